@@ -1,0 +1,6 @@
+"""Top-level alias so the reference's callers (`from environment import ...`: trainRL.py:9, train_predict.py:2-3)
+run unchanged against the MI355X-native implementation in ``occlusionenv_amd.environment``."""
+from occlusionenv_amd.environment import *  # noqa: F401,F403
+from occlusionenv_amd import environment as _impl
+
+__all__ = [n for n in dir(_impl) if not n.startswith("_")]

@@ -1,0 +1,144 @@
+/*
+ * occlusionenv_amd.h -- C ABI of the MI355X (gfx950) OcclusionEnv step() hot path.
+ *
+ * Drop-in boundary: these entry points replace, for a whole batch of N
+ * environments at once, what /root/reference/environment.py does per environment through
+ * PyTorch3D:
+ *   - camera:   environment.py:356-368 (step), :308 (reset, look_at_view_transform),
+ *               :334-335 (render)                                   -> occ_camera
+ *   - renders:  silhouette_renderer(...) x3 + phong_renderer(...)   (environment.py:310,
+ *               316-318, 370-372, 375) incl. MeshRasterizer.transform, clip_faces,
+ *               _C.rasterize_meshes (K=100 soft / K=1 hard), SoftSilhouetteShader,
+ *               HardFlatShader, observation packing (:376-378), occlusion image (:319,:373)
+ *               and loss (:322,:381), plus d loss / d(elevation, azimuth) that the
+ *               reference obtains from autograd + _C.rasterize_meshes_backward
+ *                                                                   -> occ_render
+ *   - reward bookkeeping environment.py:382-392 and the action Jacobian :356-361
+ *                                                                   -> occ_step_finish
+ *   - the operator-level replacement of _C.rasterize_meshes / _C.rasterize_meshes_backward
+ *     (K-buffer in PyTorch3D layout)                                -> occ_rasterize_meshes*
+ *
+ * Conventions: plain pointers and sizes only; every pointer is DEVICE memory owned by the
+ * caller (PyTorch's ROCm allocator in the Python host); calls are asynchronous on `stream`
+ * (a hipStream_t passed as void*; NULL = default stream); nothing is allocated, freed or
+ * synchronised inside; return value 0 = launched OK, nonzero = bad arguments / launch failure
+ * (see OCC_ERR_*).  Per-environment device-side status words report data-dependent failures
+ * (OCC_STATUS_*).
+ */
+#ifndef OCCLUSIONENV_AMD_H
+#define OCCLUSIONENV_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCC_ABI_VERSION 1
+
+/* return codes */
+#define OCC_OK 0
+#define OCC_ERR_ARG 1    /* null pointer / bad size */
+#define OCC_ERR_LAUNCH 2 /* hipLaunch failed (hipGetLastError != success) */
+
+/* per-env status bits written by the kernels (0 = fine) */
+#define OCC_STATUS_LIST_OVERFLOW 1 /* a pixel had more soft candidates than OCC_LIST_CAP */
+#define OCC_STATUS_REC_OVERFLOW 2  /* more visible (clipped) faces than record capacity */
+
+/* layout constants shared with the host */
+#define OCC_CAM_STRIDE 48  /* floats per env in the camera buffer */
+#define OCC_REC_STRIDE 40  /* floats per projected-face record */
+#define OCC_TILE 8         /* pixels per tile side: one wave64 owns an 8x8 tile */
+#define OCC_LIST_CAP 512   /* soft candidates kept per pixel before OCC_STATUS_LIST_OVERFLOW */
+#define OCC_MAX_K 128      /* largest faces_per_pixel the fused path accepts */
+
+/* occ_camera modes */
+#define OCC_CAM_STEP 0     /* environment.py:356-368: action -> el/az += 0.05*n -> C -> look_at */
+#define OCC_CAM_LOOKAT 1   /* environment.py:308: look_at_view_transform(radius, el, az)        */
+#define OCC_CAM_POSITION 2 /* environment.py:334-335: look_at_rotation(camera_position)         */
+
+/* occ_render flags */
+#define OCC_RENDER_SOFT 1  /* three soft silhouettes + occlusion image + loss */
+#define OCC_RENDER_HARD 2  /* flat-shaded RGB-D observation of the joined scene */
+#define OCC_RENDER_GRAD 4  /* also d loss / d(el, az) (needs OCC_CAM_STEP tangents) */
+
+/* GPU-resident mesh pool + per-env scene description (all device pointers). */
+typedef struct OccScene {
+    const float* pool_verts;      /* (sumV,3) */
+    const int32_t* pool_faces;    /* (sumF,3) vertex ids local to their mesh */
+    const int32_t* mesh_vert_off; /* (n_meshes+1) */
+    const int32_t* mesh_face_off; /* (n_meshes+1) */
+    const int32_t* scene_mesh;    /* (n_env,3) pool mesh id of object 1..3 (environment.py:193) */
+    const float* scene_offset;    /* (n_env,3,3) world offset of each object (environment.py:148,171) */
+    int32_t n_meshes;
+    int32_t n_env;
+    int32_t img;       /* S: image side in pixels, multiple of 8, <= 2048 */
+    int32_t rec_cap;   /* record capacity per (env, object); >= faces of the largest mesh (x2 if clipping may split) */
+} OccScene;
+
+/* Caller-allocated scratch; sizes from occ_workspace_query(). */
+typedef struct OccWorkspace {
+    float* rec;         /* (n_env,3,rec_cap,OCC_REC_STRIDE) projected face records */
+    uint32_t* rec_bbox; /* (n_env,3,rec_cap) packed tile bbox */
+    int32_t* nrec;      /* (n_env,3) */
+    int32_t* objrect;   /* (n_env,3,4) tile rect tx0,ty0,tx1,ty1 (inclusive) */
+    uint32_t* queue;    /* (16) work-queue head (zeroed by occ_render) */
+    float* lists;       /* (n_slots,OCC_LIST_CAP,64,4) per-wave candidate lists */
+    float* partials;    /* (n_env,ntiles,4) per-tile loss / gradient partial sums */
+    int32_t* status;    /* (n_env) OCC_STATUS_* bits, OR-ed in; caller clears */
+    int32_t n_slots;    /* persistent waves = blocks the tile kernel is launched with */
+} OccWorkspace;
+
+typedef struct OccWorkspaceSizes {
+    size_t rec_bytes, rec_bbox_bytes, nrec_bytes, objrect_bytes, queue_bytes, lists_bytes,
+        partials_bytes, status_bytes;
+    int32_t n_slots; /* recommended persistent-wave count for this device */
+} OccWorkspaceSizes;
+
+/* Outputs of one batched render (device pointers; any may be NULL if the flag is off). */
+typedef struct OccRenderOut {
+    float* obs;        /* (n_env,4,S,S)  RGB + view-space depth, -1 background (environment.py:376-378) */
+    float* full_state; /* (n_env,S,S,4)  i1*i2+i2*i3+i1*i3, RGB == 3 (environment.py:373) */
+    float* alphas;     /* (n_env,3,S,S)  alpha channel of the three silhouettes */
+    float* loss;       /* (n_env)        sum(full_state[...,3]^2) (environment.py:381) */
+    float* grad_elaz;  /* (n_env,2)      d loss / d(elevation, azimuth) */
+} OccRenderOut;
+
+int occ_abi_version(void);
+
+/* number of CUs of the current device (used to size n_slots); <=0 on failure. Host-side query only. */
+int occ_device_cu_count(void);
+
+int occ_workspace_query(const OccScene* scene, int n_slots, OccWorkspaceSizes* out);
+
+/*
+ * Camera for N envs.  cam: (N,OCC_CAM_STRIDE) floats =
+ *   [0..8] R row-major, [9..11] T, [12..14] C, [15..23] dR/d el, [24..26] dT/d el,
+ *   [27..35] dR/d az, [36..38] dT/d az, [39..42] d(el,az)/d(action) row-major, [43] el, [44] az.
+ * OCC_CAM_STEP:     action (N,2); el, az (N) updated IN PLACE (environment.py:360-361); radius (N).
+ * OCC_CAM_LOOKAT:   el, az, radius (N) read; action ignored.
+ * OCC_CAM_POSITION: action points to camera positions (N,3); el, az, radius ignored.
+ * cam_pos_out (N,3) receives C when non-NULL (environment.py:363-365).
+ */
+int occ_camera(int mode, const float* action, float* el, float* az, const float* radius,
+               float* cam, float* cam_pos_out, int n_env, void* stream);
+
+/* Projection + z-clipping + culling + ordered face-record build, tile rasterisation (soft x3 +
+ * hard), shading, loss and forward-mode gradient, for all envs. */
+int occ_render(const OccScene* scene, const float* cam, const OccWorkspace* ws,
+               const OccRenderOut* out, int flags, int faces_per_pixel, void* stream);
+
+/*
+ * Reward bookkeeping of step() (environment.py:381-392) for N envs:
+ *   reward = (full_reward - loss)/object_mass + (5 if loss < 0.1 else -0.2); full_reward <- loss;
+ *   done = loss < 0.1;  grad_action = -(1/object_mass) * J^T grad_elaz  (d reward / d action).
+ */
+int occ_step_finish(const float* loss, const float* grad_elaz, const float* cam,
+                    float* full_reward, const float* object_mass, float* reward, uint8_t* done,
+                    float* grad_action, int n_env, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCCLUSIONENV_AMD_H */

@@ -1,0 +1,195 @@
+"""Drop-in ``SubProcVecEnv`` module: ``SimpleVecEnv(env_fns)`` with the reference's signature and return
+contract (/root/reference/SubProcVecEnv.py:189-285), but BATCHED: instead of the sequential
+``for env_idx in range(num_envs): envs[env_idx].step(...)`` loop (SubProcVecEnv.py:209-218), the N
+environments' meshes and cameras are packed into one launch sequence on one GPU
+(``OcclusionEngine.step``).
+
+Return contract kept:
+  * ``step``  -> ``obs (N,4,S,S)``, ``rewards (N,)`` autograd-attached to ``actions`` (so that
+    ``rewards.sum().backward()`` fills ``actions.grad (N,2)``, train_predict.py:51-52), ``dones (N,) bool``,
+    ``infos`` = sequence of N dicts with ``full_state``, ``position``, ``full_reward`` and, for finished envs,
+    ``terminal_observation``; finished envs are reset (new random scene, default azimuth 0).
+  * ``reset`` -> ``(N,1,4,S,S)``: the reference stacks each env's ``(1,4,S,S)`` observation
+    (SubProcVecEnv.py:230-235), azimuth ~ U(-40, 40) *radians* per env.
+
+Deviation: scene rejection sampling in ``reset`` runs in rounds over the whole batch (one batched render per
+round) rather than env by env, so the order of ``np.random.randn()`` draws differs from the sequential loop
+when an env has to re-draw its scene.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from .baseVecEnv import VecEnv
+from .engine import OcclusionEngine
+from .environment import shared_pool
+
+
+def copy_obs_dict(obs):
+    """Shallow copy of an OrderedDict of arrays (SubProcVecEnv.py:11-18)."""
+    assert isinstance(obs, OrderedDict), "unexpected type for observations '{}'".format(type(obs))
+    return OrderedDict([(k, v) for k, v in obs.items()])
+
+
+def _space_kind(space):
+    name = type(space).__name__
+    return "dict" if name == "Dict" else ("tuple" if name == "Tuple" else "plain")
+
+
+def dict_to_obs(space, obs_dict):
+    """Internal dict representation -> the type ``space`` implies (SubProcVecEnv.py:21-40)."""
+    kind = _space_kind(space)
+    if kind == "dict":
+        return obs_dict
+    if kind == "tuple":
+        assert len(obs_dict) == len(space.spaces), "size of observation does not match size of observation space"
+        return tuple((obs_dict[i] for i in range(len(space.spaces))))
+    assert set(obs_dict.keys()) == {None}, "multiple observation keys for unstructured observation space"
+    return obs_dict[None]
+
+
+def obs_space_info(obs_space):
+    """(keys, shapes, dtypes) of a (possibly structured) observation space (SubProcVecEnv.py:43-70)."""
+    kind = _space_kind(obs_space)
+    if kind == "dict":
+        assert isinstance(obs_space.spaces, OrderedDict), "Dict space must have ordered subspaces"
+        subspaces = obs_space.spaces
+    elif kind == "tuple":
+        subspaces = {i: space for i, space in enumerate(obs_space.spaces)}
+    else:
+        assert not hasattr(obs_space, "spaces"), "Unsupported structured space '{}'".format(type(obs_space))
+        subspaces = {None: obs_space}
+    keys, shapes, dtypes = [], {}, {}
+    for key, box in subspaces.items():
+        keys.append(key)
+        shapes[key] = box.shape
+        dtypes[key] = box.dtype
+    return keys, shapes, dtypes
+
+
+class _LazyInfos(Sequence):
+    """``list[dict]`` look-alike whose dicts are built on first access (1024 dicts of tensor views per step
+    would cost more host time than the render)."""
+
+    def __init__(self, engine, full_state, loss):
+        self._e, self._fs, self._loss = engine, full_state, loss
+        self._extra = {}
+        self._made = {}
+
+    def __len__(self):
+        return self._fs.shape[0]
+
+    def set(self, i, key, value):
+        self._extra.setdefault(i, {})[key] = value
+        if i in self._made:
+            self._made[i][key] = value
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        if i not in self._made:
+            d = {"full_state": self._fs[i:i + 1], "position": self._e.camera_position[i],
+                 "full_reward": self._loss[i]}
+            d.update(self._extra.get(i, {}))
+            self._made[i] = d
+        return self._made[i]
+
+
+class SimpleVecEnv(VecEnv):
+    def __init__(self, env_fns):
+        self.envs = [fn() for fn in env_fns]
+        env = self.envs[0]
+        VecEnv.__init__(self, len(env_fns), env.observation_space, env.action_space)
+        obs_space = env.observation_space
+        self.keys, shapes, dtypes = obs_space_info(obs_space)
+        self.actions = None
+        dev = torch.device(f"cuda:{torch.cuda.current_device()}") if torch.cuda.is_available() else env.device
+        self.engine = OcclusionEngine(shared_pool(dev), self.num_envs, env.img_size, device=dev)
+        for i, e in enumerate(self.envs):
+            e._attach(self.engine, i)
+
+    def step_async(self, actions):
+        self.actions = actions
+
+    def step_wait(self):
+        eng = self.engine
+        actions = self.actions
+        if not torch.is_tensor(actions):
+            actions = torch.as_tensor(np.asarray(actions), dtype=torch.float32)
+        if actions.device != eng.device:
+            actions = actions.to(eng.device)
+        obs, rewards, dones, full_state, loss = eng.step(actions)
+        infos = _LazyInfos(eng, full_state, loss)
+        # one host sync per batched step: which envs finished + kernel status words
+        flags = torch.stack([dones.any(), eng.status.any()]).cpu()
+        if bool(flags[1]):
+            eng.check_status()
+        if bool(flags[0]):
+            for i in torch.nonzero(dones).reshape(-1).tolist():
+                # save final observation where user can get it, then reset (SubProcVecEnv.py:211-214)
+                infos.set(i, "terminal_observation", obs[i:i + 1].clone())
+                obs[i] = self.envs[i].reset()[0]
+        return obs, rewards, dones, infos
+
+    def seed(self, seed=None):
+        return [env.seed(seed + idx) for idx, env in enumerate(self.envs)]
+
+    def reset(self):
+        eng, N = self.engine, self.num_envs
+        az = torch.tensor([np.random.default_rng().uniform(low=-40, high=40) for _ in range(N)], dtype=torch.float32)
+        pending = list(range(N))
+        obs_all = torch.empty(N, 1, 4, eng.S, eng.S, dtype=torch.float32, device=eng.device)
+        for rnd in range(1, 11):  # max_resets = 10 (environment.py:288)
+            for i in pending:
+                tries = 0
+                while not self.envs[i]._new_scene():
+                    tries += 1
+                    if tries >= 1000:
+                        raise RuntimeError("reset(): could not load a scene")
+            ids = None if len(pending) == N else pending
+            obs, loss, full_state = eng.reset_render(ids, 4.0, az if ids is None else az[pending], 0.0)
+            eng.check_status()
+            ok = (loss > 0.1).cpu().tolist()
+            keep = []
+            for j, i in enumerate(pending):
+                obs_all[i, 0] = obs[j]
+                self.envs[i].image = full_state[j:j + 1]
+                if not ok[j] and rnd < 10:
+                    keep.append(i)
+            pending = keep
+            if not pending:
+                break
+        return obs_all
+
+    def close(self):
+        for env in self.envs:
+            env.close()
+
+    def get_images(self) -> Sequence[np.ndarray]:
+        return [env.render(mode="rgb_array")[0][0, ..., :3].detach().cpu().numpy() for env in self.envs]
+
+    def render(self, mode: str = "human"):
+        if self.num_envs == 1:
+            return self.envs[0].render(mode=mode)
+        return super().render(mode=mode)
+
+    def get_attr(self, attr_name, indices=None):
+        return [getattr(env_i, attr_name) for env_i in self._get_target_envs(indices)]
+
+    def set_attr(self, attr_name, value, indices=None):
+        for env_i in self._get_target_envs(indices):
+            setattr(env_i, attr_name, value)
+
+    def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
+        return [getattr(env_i, method_name)(*method_args, **method_kwargs) for env_i in self._get_target_envs(indices)]
+
+    def _get_target_envs(self, indices):
+        return [self.envs[i] for i in self._get_indices(indices)]

@@ -1,0 +1,1028 @@
+// occ_kernels.hip -- hand-written CDNA4 (gfx950) kernels for the batched OcclusionEnv step().
+//
+// What the reference does per environment through PyTorch3D (4 renders, ~200 autograd nodes,
+// /root/reference/environment.py:352-396) is done here for N environments in four launches:
+//
+//   occ_camera_kernel   one thread per env : action -> (el, az) -> C -> look_at R,T, carrying
+//                       forward-mode tangents d/d(el,az) of R and T (environment.py:356-368)
+//   occ_setup_kernel    one block per (env, object): gather pool verts, world->view->NDC
+//                       (MeshRasterizer.transform), z-clip (clip_faces), cull, per-face record
+//                       with NDC verts + tangents + invariants, ORDERED compaction (face order is
+//                       PyTorch3D's tie-break order), packed tile bbox, object tile rect
+//   occ_tile_kernel     persistent wave64 per 8x8-pixel tile (lane = pixel): on-the-fly binning by
+//                       ballot over packed bboxes, face records through the scalar cache (SGPRs),
+//                       three soft silhouettes (K nearest-z sigmoid product) + hard K=1 flat
+//                       shaded RGB-D in ONE sweep, candidate K-buffer (z, 1-p, grad) streamed to
+//                       HBM/L2 with 1-KiB coalesced rows, exact top-K-by-z selection when a pixel
+//                       has more than K candidates, occlusion image, loss and d loss/d(el,az) by
+//                       wave64 butterfly reductions
+//   occ_reduce_kernel   one wave per env: fixed-order sum of the per-tile partials
+//   occ_finish_kernel   reward bookkeeping + action Jacobian (environment.py:381-392,356-361)
+//
+// The gradient is carried in FORWARD mode (two tangent directions, el and az) through the very
+// same sweep that renders: d alpha/d theta = -(A/sigma) * sum_k p_k * d dist_k/d theta needs no
+// second pass over the K-buffer, no atomics into grad_face_verts and no saved fragments.  It
+// equals what autograd + _C.rasterize_meshes_backward produce.
+//
+// No MFMA: the path is rasterisation.  fp32 throughout.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "occ_constants.h"
+#include "occlusionenv_amd.h"
+
+namespace occ {
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fmin3(float a, float b, float c) { return fminf(fminf(a, b), c); }
+__device__ __forceinline__ float fmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float clamp01(float t) { return fminf(fmaxf(t, 0.0f), 1.0f); }
+
+// Read-only data produced by an EARLIER launch (face records, bboxes, rects) is read through the
+// constant address space: with a wave-uniform address hipcc then emits s_load_dwordx8/x16 into
+// SGPRs (scalar cache) instead of 64 redundant vector loads.
+typedef const __attribute__((address_space(4))) float* cfptr;
+typedef const __attribute__((address_space(4))) int* ciptr;
+__device__ __forceinline__ cfptr as_const(const float* p) { return (cfptr)(uintptr_t)p; }
+__device__ __forceinline__ ciptr as_const(const int* p) { return (ciptr)(uintptr_t)p; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// camera: dual numbers with two tangent directions (d/d el, d/d az)
+// ------------------------------------------------------------------------------------------
+struct D2 {
+    float v, e, a;
+};
+__device__ __forceinline__ D2 dconst(float v) { return {v, 0.f, 0.f}; }
+__device__ __forceinline__ D2 operator+(D2 x, D2 y) { return {x.v + y.v, x.e + y.e, x.a + y.a}; }
+__device__ __forceinline__ D2 operator-(D2 x, D2 y) { return {x.v - y.v, x.e - y.e, x.a - y.a}; }
+__device__ __forceinline__ D2 operator-(D2 x) { return {-x.v, -x.e, -x.a}; }
+__device__ __forceinline__ D2 operator*(D2 x, D2 y) {
+    return {x.v * y.v, x.e * y.v + x.v * y.e, x.a * y.v + x.v * y.a};
+}
+__device__ __forceinline__ D2 operator/(D2 x, D2 y) {
+    const float q = x.v / y.v;
+    return {q, (x.e - q * y.e) / y.v, (x.a - q * y.a) / y.v};
+}
+__device__ __forceinline__ D2 dsin(D2 x) {
+    const float s = sinf(x.v), c = cosf(x.v);
+    return {s, c * x.e, c * x.a};
+}
+__device__ __forceinline__ D2 dcos(D2 x) {
+    const float s = sinf(x.v), c = cosf(x.v);
+    return {c, -s * x.e, -s * x.a};
+}
+// F.normalize(v, eps): v / max(||v||, eps)    [P3D look_at_rotation, SURVEY A.1]
+__device__ __forceinline__ void dnormalize3(D2* v, float eps) {
+    const D2 n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    const float n = sqrtf(n2.v);
+    D2 nn;
+    if (n > eps) {
+        const float h = 0.5f / n;
+        nn = {n, h * n2.e, h * n2.a};
+    } else {
+        nn = dconst(eps);
+    }
+    v[0] = v[0] / nn;
+    v[1] = v[1] / nn;
+    v[2] = v[2] / nn;
+}
+__device__ __forceinline__ void dcross(const D2* a, const D2* b, D2* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+__global__ __launch_bounds__(64) void occ_camera_kernel(int mode, const float* __restrict__ action,
+                                                        float* __restrict__ el_io, float* __restrict__ az_io,
+                                                        const float* __restrict__ radius, float* __restrict__ cam,
+                                                        float* __restrict__ cam_pos_out, int n_env) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_env) return;
+    float* c = cam + (size_t)n * OCC_CAM_STRIDE;
+    D2 C[3];
+    float J[4] = {0.f, 0.f, 0.f, 0.f};
+    float el_new = 0.f, az_new = 0.f;
+    if (mode == OCC_CAM_STEP) {
+        // environment.py:356-365
+        const float a0 = action[2 * n], a1 = action[2 * n + 1];
+        const float nrm = sqrtf(a0 * a0 + a1 * a1);
+        float n0 = a0, n1 = a1;
+        float j00 = 1.f, j01 = 0.f, j10 = 0.f, j11 = 1.f;  // d n_i / d a_j
+        if (nrm != 0.0f) {
+            n0 = a0 / nrm;
+            n1 = a1 / nrm;
+            j00 = (1.f - n0 * n0) / nrm;
+            j01 = (-n0 * n1) / nrm;
+            j10 = j01;
+            j11 = (1.f - n1 * n1) / nrm;
+        }
+        el_new = el_io[n] + n0 * kStepSize;
+        az_new = az_io[n] + n1 * kStepSize;
+        el_io[n] = el_new;
+        az_io[n] = az_new;
+        J[0] = kStepSize * j00;
+        J[1] = kStepSize * j01;
+        J[2] = kStepSize * j10;
+        J[3] = kStepSize * j11;
+        const D2 el = {el_new, 1.f, 0.f}, az = {az_new, 0.f, 1.f};
+        const D2 r = dconst(radius[n]);
+        const D2 rs = r * dsin(az);
+        C[0] = rs * dcos(el);
+        C[1] = rs * dsin(el);
+        C[2] = r * dcos(az);
+    } else if (mode == OCC_CAM_LOOKAT) {
+        // environment.py:308 -> [P3D] camera_position_from_spherical_angles(degrees=False)
+        el_new = el_io[n];
+        az_new = az_io[n];
+        const float r = radius[n];
+        C[0] = dconst(r * cosf(el_new) * sinf(az_new));
+        C[1] = dconst(r * sinf(el_new));
+        C[2] = dconst(r * cosf(el_new) * cosf(az_new));
+    } else {
+        C[0] = dconst(action[3 * n]);
+        C[1] = dconst(action[3 * n + 1]);
+        C[2] = dconst(action[3 * n + 2]);
+    }
+    // [P3D] look_at_rotation(C, at=0, up=+Y)
+    D2 z[3] = {-C[0], -C[1], -C[2]};
+    dnormalize3(z, kLookAtEps);
+    const D2 up[3] = {dconst(0.f), dconst(1.f), dconst(0.f)};
+    D2 x[3], y[3];
+    dcross(up, z, x);
+    dnormalize3(x, kLookAtEps);
+    dcross(z, x, y);
+    dnormalize3(y, kLookAtEps);
+    if (fabsf(x[0].v) <= kLookAtClose && fabsf(x[1].v) <= kLookAtClose && fabsf(x[2].v) <= kLookAtClose) {
+        dcross(y, z, x);
+        dnormalize3(x, kLookAtEps);
+    }
+    // R[i][j]: columns are x, y, z ; T = -R^T C
+    const D2* ax[3] = {x, y, z};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const D2 t = -(ax[j][0] * C[0] + ax[j][1] * C[1] + ax[j][2] * C[2]);
+        c[C_T + j] = t.v;
+        c[C_DT_EL + j] = t.e;
+        c[C_DT_AZ + j] = t.a;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            c[C_R + i * 3 + j] = ax[j][i].v;
+            c[C_DR_EL + i * 3 + j] = ax[j][i].e;
+            c[C_DR_AZ + i * 3 + j] = ax[j][i].a;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c[C_C + i] = C[i].v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[C_J + i] = J[i];
+    c[C_EL] = el_new;
+    c[C_AZ] = az_new;
+    c[45] = c[46] = c[47] = 0.f;
+    if (cam_pos_out) {
+        cam_pos_out[3 * n] = C[0].v;
+        cam_pos_out[3 * n + 1] = C[1].v;
+        cam_pos_out[3 * n + 2] = C[2].v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// setup: projection, z-clipping, culling, record build with ordered compaction
+// ------------------------------------------------------------------------------------------
+struct PVert {      // one projected vertex
+    float x, y, z;  // x_ndc, y_ndc, z_view
+    float t[4];     // d x/d el, d y/d el, d x/d az, d y/d az
+};
+
+struct VVert {  // view-space vertex with tangents
+    float v[3];
+    float de[3], da[3];
+};
+
+template <bool GRAD>
+__device__ __forceinline__ PVert project(const VVert& q) {
+    // [P3D] x_ndc = x_view * s / z_view  
+    PVert p;
+    const float iz = 1.0f / q.v[2];
+    p.x = q.v[0] * kProjScale * iz;
+    p.y = q.v[1] * kProjScale * iz;
+    p.z = q.v[2];
+    if (GRAD) {
+        p.t[0] = (kProjScale * q.de[0] - p.x * q.de[2]) * iz;
+        p.t[1] = (kProjScale * q.de[1] - p.y * q.de[2]) * iz;
+        p.t[2] = (kProjScale * q.da[0] - p.x * q.da[2]) * iz;
+        p.t[3] = (kProjScale * q.da[1] - p.y * q.da[2]) * iz;
+    } else {
+        p.t[0] = p.t[1] = p.t[2] = p.t[3] = 0.f;
+    }
+    return p;
+}
+
+// [P3D] clip_faces: intersection of edge (a -> b) with z = kZClip, weight detached
+template <bool GRAD>
+__device__ __forceinline__ PVert cut_edge(const VVert& a, const VVert& b) {
+    PVert p;
+    const float w = (a.v[2] - kZClip) / (a.v[2] - b.v[2]);
+    const float iw = 1.0f - w;
+    const float ic = 1.0f / kZClip;
+    p.z = a.v[2] * iw + b.v[2] * w;
+    p.x = (kProjScale * a.v[0] * iw + kProjScale * b.v[0] * w) * ic;
+    p.y = (kProjScale * a.v[1] * iw + kProjScale * b.v[1] * w) * ic;
+    if (GRAD) {
+        p.t[0] = (kProjScale * a.de[0] * iw + kProjScale * b.de[0] * w) * ic;
+        p.t[1] = (kProjScale * a.de[1] * iw + kProjScale * b.de[1] * w) * ic;
+        p.t[2] = (kProjScale * a.da[0] * iw + kProjScale * b.da[0] * w) * ic;
+        p.t[3] = (kProjScale * a.da[1] * iw + kProjScale * b.da[1] * w) * ic;
+    } else {
+        p.t[0] = p.t[1] = p.t[2] = p.t[3] = 0.f;
+    }
+    return p;
+}
+
+struct Tri {
+    PVert v[3];
+    uint32_t bbox;  // packed tile bbox
+    int tx0, ty0, tx1, ty1;
+};
+
+// returns false if the triangle can never be matched to a pixel (culled / degenerate / off screen)
+__device__ __forceinline__ bool finish_tri(Tri& t, int S) {
+    const float x0 = t.v[0].x, y0 = t.v[0].y, x1 = t.v[1].x, y1 = t.v[1].y, x2 = t.v[2].x, y2 = t.v[2].y;
+    // [P3D] face_area = EdgeFunction(v0; v1, v2); back faces are culled (environment.py:253,271)
+    const float area = (x0 - x1) * (y2 - y1) - (y0 - y1) * (x2 - x1);
+    if (!(area > kEpsilon)) return false;  // back face, zero area or NaN
+    if (fmax3(t.v[0].z, t.v[1].z, t.v[2].z) < 0.0f) return false;
+    const float bx0 = fmin3(x0, x1, x2) - kSqrtBlur, bx1 = fmax3(x0, x1, x2) + kSqrtBlur;
+    const float by0 = fmin3(y0, y1, y2) - kSqrtBlur, by1 = fmax3(y0, y1, y2) + kSqrtBlur;
+    const float lim = 1.0f - 1.0f / (float)S;  // outermost pixel centre
+    if (bx1 < -lim || bx0 > lim || by1 < -lim || by0 > lim) return false;
+    // pixel index of an NDC coordinate: u(f) = (S-1) - ((f+1)*S - 1)/2   (decreasing)
+    const float fS = (float)S;
+    auto u = [&](float f) { return (fS - 1.0f) - ((f + 1.0f) * fS - 1.0f) * 0.5f; };
+    int xl = (int)floorf(u(bx1) - 0.01f), xh = (int)ceilf(u(bx0) + 0.01f);
+    int yl = (int)floorf(u(by1) - 0.01f), yh = (int)ceilf(u(by0) + 0.01f);
+    xl = max(xl, 0);
+    yl = max(yl, 0);
+    xh = min(xh, S - 1);
+    yh = min(yh, S - 1);
+    if (xl > xh || yl > yh) return false;
+    t.tx0 = xl / OCC_TILE;
+    t.tx1 = xh / OCC_TILE;
+    t.ty0 = yl / OCC_TILE;
+    t.ty1 = yh / OCC_TILE;
+    t.bbox = (uint32_t)t.tx0 | ((uint32_t)t.ty0 << 8) | ((uint32_t)t.tx1 << 16) | ((uint32_t)t.ty1 << 24);
+    return true;
+}
+
+template <bool GRAD>
+__device__ __forceinline__ void write_record(float* __restrict__ r, uint32_t* __restrict__ bb, const Tri& t,
+                                             int face_id, int flags) {
+    const float x0 = t.v[0].x, y0 = t.v[0].y, x1 = t.v[1].x, y1 = t.v[1].y, x2 = t.v[2].x, y2 = t.v[2].y;
+    float o[OCC_REC_STRIDE];
+#pragma unroll
+    for (int i = 0; i < OCC_REC_STRIDE; ++i) o[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o[3 * k] = t.v[k].x;
+        o[3 * k + 1] = t.v[k].y;
+        o[3 * k + 2] = t.v[k].z;
+        if (GRAD) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[R_TAN + 4 * k + j] = t.v[k].t[j];
+        }
+    }
+    o[R_ID] = __int_as_float(face_id);
+    o[R_FLAGS] = __int_as_float(flags);
+    // [P3D] BarycentricCoordsForward: area = EdgeFunction(v2; v0, v1) + kEpsilon
+    const float area = (x2 - x0) * (y1 - y0) - (y2 - y0) * (x1 - x0) + kEpsilon;
+    o[R_INV_AREA] = 1.0f / area;
+    o[R_BX0] = fmin3(x0, x1, x2) - kSqrtBlur;
+    o[R_BX1] = fmax3(x0, x1, x2) + kSqrtBlur;
+    o[R_BY0] = fmin3(y0, y1, y2) - kSqrtBlur;
+    o[R_BY1] = fmax3(y0, y1, y2) + kSqrtBlur;
+    const float l01 = (x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0);
+    const float l02 = (x2 - x0) * (x2 - x0) + (y2 - y0) * (y2 - y0);
+    const float l12 = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
+    o[R_IL01] = l01 <= kEpsilon ? -1.0f : 1.0f / l01;
+    o[R_IL02] = l02 <= kEpsilon ? -1.0f : 1.0f / l02;
+    o[R_IL12] = l12 <= kEpsilon ? -1.0f : 1.0f / l12;
+    o[R_ILE01] = 1.0f / (l01 + kEpsilon);
+    o[R_ILE02] = 1.0f / (l02 + kEpsilon);
+    o[R_ILE12] = 1.0f / (l12 + kEpsilon);
+    float4* r4 = reinterpret_cast<float4*>(r);
+#pragma unroll
+    for (int i = 0; i < OCC_REC_STRIDE / 4; ++i) r4[i] = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+    *bb = t.bbox;
+}
+
+template <bool GRAD>
+__global__ __launch_bounds__(256) void occ_setup_kernel(OccScene sc, const float* __restrict__ cam, OccWorkspace ws) {
+    __shared__ int s_wcnt[4];
+    __shared__ int s_rect[4];
+    const int eo = blockIdx.x;  // env*3 + object
+    const int env = eo / 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mesh = sc.scene_mesh[eo];
+    const int vo = sc.mesh_vert_off[mesh];
+    const int fo = sc.mesh_face_off[mesh];
+    const int nF = sc.mesh_face_off[mesh + 1] - fo;
+    const float ox = sc.scene_offset[eo * 3], oy = sc.scene_offset[eo * 3 + 1], oz = sc.scene_offset[eo * 3 + 2];
+    const float* __restrict__ c = cam + (size_t)env * OCC_CAM_STRIDE;
+    float R[9], T[3], dRe[9], dTe[3], dRa[9], dTa[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        R[i] = c[C_R + i];
+        dRe[i] = GRAD ? c[C_DR_EL + i] : 0.f;
+        dRa[i] = GRAD ? c[C_DR_AZ + i] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        T[i] = c[C_T + i];
+        dTe[i] = GRAD ? c[C_DT_EL + i] : 0.f;
+        dTa[i] = GRAD ? c[C_DT_AZ + i] : 0.f;
+    }
+    if (tid == 0) {
+        s_rect[0] = 1 << 20;
+        s_rect[1] = 1 << 20;
+        s_rect[2] = -1;
+        s_rect[3] = -1;
+    }
+    __syncthreads();
+    float* __restrict__ rec = ws.rec + (size_t)eo * sc.rec_cap * OCC_REC_STRIDE;
+    uint32_t* __restrict__ bbs = ws.rec_bbox + (size_t)eo * sc.rec_cap;
+    int total = 0;
+    bool overflow = false;
+    for (int base = 0; base < nF; base += 256) {
+        const int f = base + tid;
+        int cnt = 0;
+        Tri tri[2];
+        int flags0 = 0, flags1 = 0;
+        if (f < nF) {
+            VVert q[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int vi = sc.pool_faces[(size_t)(fo + f) * 3 + k];
+                const float* pv = sc.pool_verts + (size_t)(vo + vi) * 3;
+                // environment.py:148,171: verts + offset in f32
+                const float wx = pv[0] + ox, wy = pv[1] + oy, wz = pv[2] + oz;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    q[k].v[j] = wx * R[j] + wy * R[3 + j] + wz * R[6 + j] + T[j];
+                    if (GRAD) {
+                        q[k].de[j] = wx * dRe[j] + wy * dRe[3 + j] + wz * dRe[6 + j] + dTe[j];
+                        q[k].da[j] = wx * dRa[j] + wy * dRa[3 + j] + wz * dRa[6 + j] + dTa[j];
+                    }
+                }
+            }
+            const bool b0 = q[0].v[2] < kZClip, b1 = q[1].v[2] < kZClip, b2 = q[2].v[2] < kZClip;
+            const int nb = (int)b0 + (int)b1 + (int)b2;
+            if (nb == 0) {
+                tri[0].v[0] = project<GRAD>(q[0]);
+                tri[0].v[1] = project<GRAD>(q[1]);
+                tri[0].v[2] = project<GRAD>(q[2]);
+                cnt = finish_tri(tri[0], sc.img) ? 1 : 0;
+            } else if (nb == 2) {
+                // case 3: p1 = the vertex in front; new triangle (p4, p5, p1)
+                const int i1 = !b0 ? 0 : (!b1 ? 1 : 2);
+                const int i2 = (i1 + 1) % 3, i3 = (i1 + 2) % 3;
+                tri[0].v[0] = cut_edge<GRAD>(q[i1], q[i2]);
+                tri[0].v[1] = cut_edge<GRAD>(q[i1], q[i3]);
+                tri[0].v[2] = project<GRAD>(q[i1]);
+                cnt = finish_tri(tri[0], sc.img) ? 1 : 0;
+            } else if (nb == 1) {
+                // case 4: p1 = the vertex behind; quad -> (p4, p2, p5), (p5, p2, p3)
+                const int i1 = b0 ? 0 : (b1 ? 1 : 2);
+                const int i2 = (i1 + 1) % 3, i3 = (i1 + 2) % 3;
+                const PVert p4 = cut_edge<GRAD>(q[i1], q[i2]);
+                const PVert p5 = cut_edge<GRAD>(q[i1], q[i3]);
+                const PVert p2 = project<GRAD>(q[i2]);
+                const PVert p3 = project<GRAD>(q[i3]);
+                Tri ta, tb;
+                ta.v[0] = p4; ta.v[1] = p2; ta.v[2] = p5;
+                tb.v[0] = p5; tb.v[1] = p2; tb.v[2] = p3;
+                const bool oka = finish_tri(ta, sc.img), okb = finish_tri(tb, sc.img);
+                if (oka && okb) {
+                    tri[0] = ta; tri[1] = tb; cnt = 2;
+                    flags0 = FLAG_PAIR_FIRST; flags1 = FLAG_PAIR_SECOND;
+                } else if (oka) {
+                    tri[0] = ta; cnt = 1;
+                } else if (okb) {
+                    tri[0] = tb; cnt = 1;
+                }
+            }
+        }
+        // ordered compaction: exclusive prefix of cnt in {0,1,2} over the block
+        const unsigned long long m1 = __ballot(cnt >= 1), m2 = __ballot(cnt == 2);
+        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const int pre = __popcll(m1 & lt) + __popcll(m2 & lt);
+        if (lane == 0) s_wcnt[wave] = __popcll(m1) + __popcll(m2);
+        __syncthreads();
+        int woff = 0, itot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int cw = s_wcnt[w];
+            if (w < wave) woff += cw;
+            itot += cw;
+        }
+        const int pos = total + woff + pre;
+        if (cnt >= 1) {
+            if (pos + cnt <= sc.rec_cap) {
+                write_record<GRAD>(rec + (size_t)pos * OCC_REC_STRIDE, bbs + pos, tri[0], f, flags0);
+                if (cnt == 2) write_record<GRAD>(rec + (size_t)(pos + 1) * OCC_REC_STRIDE, bbs + pos + 1, tri[1], f, flags1);
+                int x0 = tri[0].tx0, y0 = tri[0].ty0, x1 = tri[0].tx1, y1 = tri[0].ty1;
+                if (cnt == 2) {
+                    x0 = min(x0, tri[1].tx0); y0 = min(y0, tri[1].ty0);
+                    x1 = max(x1, tri[1].tx1); y1 = max(y1, tri[1].ty1);
+                }
+                atomicMin(&s_rect[0], x0);
+                atomicMin(&s_rect[1], y0);
+                atomicMax(&s_rect[2], x1);
+                atomicMax(&s_rect[3], y1);
+            } else {
+                overflow = true;
+            }
+        }
+        total += itot;
+        __syncthreads();
+    }
+    if (overflow) atomicOr(&ws.status[env], OCC_STATUS_REC_OVERFLOW);
+    if (tid == 0) {
+        ws.nrec[eo] = min(total, sc.rec_cap);
+        ws.objrect[eo * 4 + 0] = s_rect[0];
+        ws.objrect[eo * 4 + 1] = s_rect[1];
+        ws.objrect[eo * 4 + 2] = s_rect[2];
+        ws.objrect[eo * 4 + 3] = s_rect[3];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// tile rasteriser
+// ------------------------------------------------------------------------------------------
+struct Cand {
+    bool cand;    // soft candidate (inside, or within blur)
+    bool inside;  // pixel centre strictly inside (hard candidate)
+    float z;      // soft depth (clipped barycentrics)
+    float zh;     // hard depth (unclipped barycentrics)
+    float ad;     // |squared distance|
+    float q;      // 1 - sigmoid(-d/sigma)
+    float ge, ga; // p * d(d)/d el, p * d(d)/d az
+};
+
+// Evaluate one projected face (wave-uniform record r -> SGPRs) at this lane's pixel centre.
+// Restates [P3D] CheckPixelInsideFace and, for GRAD, the dists part of
+// RasterizeMeshesBackward (A.5) pushed forward along the two vertex tangents.
+template <bool SOFT, bool GRAD>
+__device__ __forceinline__ void eval_face(cfptr r, float xf, float yf, Cand& c) {
+    c.cand = false;
+    c.inside = false;
+    c.z = c.zh = c.ad = 0.f;
+    c.q = 1.f;
+    c.ge = c.ga = 0.f;
+    const bool inb = (r[R_BX0] <= xf) && (xf <= r[R_BX1]) && (r[R_BY0] <= yf) && (yf <= r[R_BY1]);
+    if (!inb) return;
+    const float x0 = r[R_X0], y0 = r[R_Y0], z0 = r[R_Z0];
+    const float x1 = r[R_X1], y1 = r[R_Y1], z1 = r[R_Z1];
+    const float x2 = r[R_X2], y2 = r[R_Y2], z2 = r[R_Z2];
+    const float dx0 = xf - x0, dy0 = yf - y0, dx1 = xf - x1, dy1 = yf - y1, dx2 = xf - x2, dy2 = yf - y2;
+    const float ex01 = x1 - x0, ey01 = y1 - y0, ex02 = x2 - x0, ey02 = y2 - y0, ex12 = x2 - x1, ey12 = y2 - y1;
+    const float inv_area = r[R_INV_AREA];
+    // barycentrics: E(p;v1,v2), E(p;v2,v0), E(p;v0,v1) over area
+    const float b0 = (dx1 * ey12 - dy1 * ex12) * inv_area;
+    const float b1 = (dy2 * ex02 - dx2 * ey02) * inv_area;
+    const float b2 = (dx0 * ey01 - dy0 * ex01) * inv_area;
+    // perspective correction
+    const float w0 = b0 * z1 * z2, w1 = z0 * b1 * z2, w2 = z0 * z1 * b2;
+    const float rden = frcp(fmaxf(w0 + w1 + w2, kEpsilon));
+    const float p0 = w0 * rden, p1 = w1 * rden, p2 = w2 * rden;
+    const bool inside = (p0 > 0.0f) && (p1 > 0.0f) && (p2 > 0.0f);
+    c.zh = p0 * z0 + p1 * z1 + p2 * z2;
+    c.inside = inside && !(c.zh < 0.0f);
+    if (!SOFT) return;
+    // clipped barycentrics -> soft depth
+    float c0 = fmaxf(p0, 0.f), c1 = fmaxf(p1, 0.f), c2 = fmaxf(p2, 0.f);
+    const float rs = frcp(fmaxf(c0 + c1 + c2, kBaryClipMin));
+    c0 *= rs;
+    c1 *= rs;
+    c2 *= rs;
+    const float pz = c0 * z0 + c1 * z1 + c2 * z2;
+    // squared distance to the three edges (v0,v1), (v0,v2), (v1,v2)
+    const float il01 = r[R_IL01], il02 = r[R_IL02], il12 = r[R_IL12];
+    const float dot01 = ex01 * dx0 + ey01 * dy0;
+    const float dot02 = ex02 * dx0 + ey02 * dy0;
+    const float dot12 = ex12 * dx1 + ey12 * dy1;
+    const float t01 = il01 < 0.f ? 1.0f : clamp01(dot01 * il01);
+    const float t02 = il02 < 0.f ? 1.0f : clamp01(dot02 * il02);
+    const float t12 = il12 < 0.f ? 1.0f : clamp01(dot12 * il12);
+    const float qx01 = t01 * ex01 - dx0, qy01 = t01 * ey01 - dy0;
+    const float qx02 = t02 * ex02 - dx0, qy02 = t02 * ey02 - dy0;
+    const float qx12 = t12 * ex12 - dx1, qy12 = t12 * ey12 - dy1;
+    const float d01 = qx01 * qx01 + qy01 * qy01;
+    const float d02 = qx02 * qx02 + qy02 * qy02;
+    const float d12 = qx12 * qx12 + qy12 * qy12;
+    const float dist = fmin3(d01, d02, d12);
+    const bool cand = !(pz < 0.0f) && (inside || dist < kBlurRadius);
+    c.cand = cand;
+    c.z = pz;
+    c.ad = dist;
+    const float sd = inside ? -dist : dist;
+    // [P3D] sigmoid_alpha_blend: p = sigmoid(-d/sigma) = 1/(1+exp(d/sigma))  
+    const float e = __expf(sd * kInvSigma);
+    const float p = frcp(1.0f + e);
+    c.q = 1.0f - p;
+    if (GRAD) {
+        // closest edge with [P3D] tie order e01, e02, e12; t recomputed with (l2 + eps) like the backward
+        const bool s01 = (d01 <= d02) && (d01 <= d12);
+        const bool s02 = !s01 && (d02 <= d01) && (d02 <= d12);
+        const bool s12 = !s01 && !s02 && (d12 <= d01) && (d12 <= d02);
+        const float bax = s01 ? ex01 : (s02 ? ex02 : ex12);
+        const float bay = s01 ? ey01 : (s02 ? ey02 : ey12);
+        const float dotv = s01 ? dot01 : (s02 ? dot02 : dot12);
+        const float ile = s01 ? r[R_ILE01] : (s02 ? r[R_ILE02] : r[R_ILE12]);
+        const float pax = s12 ? dx1 : dx0, pay = s12 ? dy1 : dy0;
+        const float tb = clamp01(dotv * ile);
+        const float gx = 2.0f * (tb * bax - pax), gy = 2.0f * (tb * bay - pay);  // 2 (proj - p)
+        // tangent of the projected point: (1-t) a' + t b'
+        const float a_xe = s12 ? r[R_TAN + 4] : r[R_TAN + 0], a_ye = s12 ? r[R_TAN + 5] : r[R_TAN + 1];
+        const float a_xa = s12 ? r[R_TAN + 6] : r[R_TAN + 2], a_ya = s12 ? r[R_TAN + 7] : r[R_TAN + 3];
+        const float b_xe = s01 ? r[R_TAN + 4] : r[R_TAN + 8], b_ye = s01 ? r[R_TAN + 5] : r[R_TAN + 9];
+        const float b_xa = s01 ? r[R_TAN + 6] : r[R_TAN + 10], b_ya = s01 ? r[R_TAN + 7] : r[R_TAN + 11];
+        const float mxe = a_xe + tb * (b_xe - a_xe), mye = a_ye + tb * (b_ye - a_ye);
+        const float mxa = a_xa + tb * (b_xa - a_xa), mya = a_ya + tb * (b_ya - a_ya);
+        const float any = (s01 || s02 || s12) ? 1.0f : 0.0f;
+        const float sp = (inside ? -p : p) * any;
+        c.ge = sp * (gx * mxe + gy * mye);
+        c.ga = sp * (gx * mxa + gy * mya);
+    }
+}
+
+__device__ __forceinline__ uint32_t zkey(float z) {
+    const uint32_t b = __float_as_uint(z);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+struct TileParams {
+    OccScene sc;
+    OccWorkspace ws;
+    OccRenderOut out;
+    const float* cam;
+    int K;
+    int ntx;  // tiles per image side
+};
+
+constexpr int kChunk = 4;  // tiles dequeued per atomic
+
+template <bool SOFT, bool HARD, bool GRAD>
+__global__ __launch_bounds__(64) void occ_tile_kernel(TileParams P) {
+    const int lane = threadIdx.x;
+    const int S = P.sc.img;
+    const int ntx = P.ntx, ntiles = ntx * ntx;
+    const int total_items = P.sc.n_env * ntiles;
+    float4* __restrict__ mylist = reinterpret_cast<float4*>(P.ws.lists) + (size_t)blockIdx.x * OCC_LIST_CAP * 64;
+    const float fS = (float)S;
+    const int cap = P.sc.rec_cap;
+    const int K = P.K;
+
+    for (;;) {
+        int start = 0;
+        if (lane == 0) start = (int)atomicAdd(P.ws.queue, (uint32_t)kChunk);
+        start = __builtin_amdgcn_readfirstlane(start);
+        if (start >= total_items) break;
+        const int stop = min(start + kChunk, total_items);
+        for (int item = start; item < stop; ++item) {
+            const int env = item / ntiles;
+            const int t = item - env * ntiles;
+            const int ty = t / ntx, tx = t - ty * ntx;
+            const int xi = tx * OCC_TILE + (lane & 7), yi = ty * OCC_TILE + (lane >> 3);
+            // [P3D] pixel centre in NDC, +X left, +Y up
+            const float xf = -1.0f + (2.0f * (float)(S - 1 - xi) + 1.0f) / fS;
+            const float yf = -1.0f + (2.0f * (float)(S - 1 - yi) + 1.0f) / fS;
+            float alpha[3] = {0.f, 0.f, 0.f};
+            float dae[3] = {0.f, 0.f, 0.f}, daa[3] = {0.f, 0.f, 0.f};
+            float hz = 3.0e38f;
+            int hrec = -1;  // (object * cap + record) of the nearest hard face
+            bool list_ovf = false;
+
+#pragma unroll 1
+            for (int o = 0; o < 3; ++o) {
+                const int eo = env * 3 + o;
+                ciptr rect = as_const(P.ws.objrect + eo * 4);
+                if (tx < rect[0] || ty < rect[1] || tx > rect[2] || ty > rect[3]) continue;
+                const int n = as_const(P.ws.nrec + eo)[0];
+                cfptr recs = as_const(P.ws.rec + (size_t)eo * cap * OCC_REC_STRIDE);
+                const uint32_t* __restrict__ bbs = P.ws.rec_bbox + (size_t)eo * cap;
+                int count = 0;
+                float prod = 1.0f, sge = 0.f, sga = 0.f;
+                bool skip0 = false;
+
+                auto commit = [&](bool cnd, float z, float q, float ge, float ga) {
+                    if (cnd) {
+                        if (count < OCC_LIST_CAP) {
+                            mylist[(size_t)count * 64 + lane] = make_float4(z, q, ge, ga);
+                        } else {
+                            list_ovf = true;
+                        }
+                        count += 1;
+                        prod *= q;
+                        sge += ge;
+                        sga += ga;
+                    }
+                };
+                auto hard_update = [&](const Cand& c, int j) {
+                    if (HARD) {
+                        if (c.inside && c.zh < hz) {
+                            hz = c.zh;
+                            hrec = o * cap + j;
+                        }
+                    }
+                };
+
+                for (int c0 = 0; c0 < n; c0 += 64) {
+                    const int jj = c0 + lane;
+                    uint32_t bb = 0x000000FFu;  // tx0 = 255 > tx1 = 0: never overlaps
+                    if (jj < n) bb = bbs[jj];
+                    const int bx0 = bb & 0xFF, by0 = (bb >> 8) & 0xFF, bx1 = (bb >> 16) & 0xFF, by1 = bb >> 24;
+                    const bool hit = (bx0 <= tx) && (tx <= bx1) && (by0 <= ty) && (ty <= by1);
+                    unsigned long long mask = __ballot(hit);
+                    if (skip0) {
+                        mask &= ~1ull;
+                        skip0 = false;
+                    }
+                    while (mask) {
+                        const int bit = __builtin_ctzll(mask);
+                        mask &= mask - 1;
+                        const int j = c0 + bit;
+                        cfptr r = recs + (size_t)j * OCC_REC_STRIDE;
+                        const int flags = __float_as_int(r[R_FLAGS]);
+                        Cand c1;
+                        eval_face<SOFT, GRAD>(r, xf, yf, c1);
+                        hard_update(c1, j);
+                        bool pair = false;
+                        if (flags & FLAG_PAIR_FIRST) {
+                            // clipped quad split in two: only the nearer-in-|d| of the pair
+                            // may enter a pixel's list
+                            bool second_hit;
+                            if (bit < 63) {
+                                second_hit = (mask >> (bit + 1)) & 1ull;
+                                if (second_hit) mask &= ~(1ull << (bit + 1));
+                            } else {
+                                second_hit = false;
+                                if (j + 1 < n) {
+                                    const uint32_t b2 = bbs[j + 1];
+                                    second_hit = ((int)(b2 & 0xFF) <= tx) && (tx <= (int)((b2 >> 16) & 0xFF)) &&
+                                                 ((int)((b2 >> 8) & 0xFF) <= ty) && (ty <= (int)(b2 >> 24));
+                                }
+                                if (second_hit) skip0 = true;
+                            }
+                            pair = second_hit;
+                        }
+                        if (pair) {
+                            Cand c2;
+                            eval_face<SOFT, GRAD>(r + OCC_REC_STRIDE, xf, yf, c2);
+                            hard_update(c2, j + 1);
+                            if (SOFT) {
+                                const bool take2 = c2.cand && (!c1.cand || c2.ad < c1.ad);
+                                const bool any = c1.cand || c2.cand;
+                                commit(any, take2 ? c2.z : c1.z, take2 ? c2.q : c1.q, take2 ? c2.ge : c1.ge,
+                                       take2 ? c2.ga : c1.ga);
+                            }
+                        } else if (SOFT) {
+                            commit(c1.cand, c1.z, c1.q, c1.ge, c1.ga);
+                        }
+                    }
+                }
+
+                if (SOFT) {
+                    // more than K candidates: keep the K nearest in z (ties: earlier face first), SURVEY A.4
+                    const bool ovf = count > K;
+                    if (__ballot(ovf)) {
+                        const int cnt = min(count, OCC_LIST_CAP);
+                        const int maxc = wave_max_i(ovf ? cnt : 0);
+                        uint32_t T = 0;
+                        for (int bitp = 31; bitp >= 0; --bitp) {
+                            const uint32_t candT = T | (1u << bitp);
+                            int cless = 0;
+                            for (int e = 0; e < maxc; ++e) {
+                                if (ovf && e < cnt) {
+                                    const float z = mylist[(size_t)e * 64 + lane].x;
+                                    cless += (zkey(z) < candT) ? 1 : 0;
+                                }
+                            }
+                            if (cless < K) T = candT;
+                        }
+                        // T = K-th smallest key.  Take all below, then the first (K - nless) equal ones.
+                        int nless = 0;
+                        for (int e = 0; e < maxc; ++e) {
+                            if (ovf && e < cnt) nless += (zkey(mylist[(size_t)e * 64 + lane].x) < T) ? 1 : 0;
+                        }
+                        int take = K - nless;
+                        float pr = 1.0f, se = 0.f, sa = 0.f;
+                        for (int e = 0; e < maxc; ++e) {
+                            if (ovf && e < cnt) {
+                                const float4 v = mylist[(size_t)e * 64 + lane];
+                                const uint32_t k = zkey(v.x);
+                                bool inc = k < T;
+                                if (k == T && take > 0) {
+                                    inc = true;
+                                    take -= 1;
+                                }
+                                if (inc) {
+                                    pr *= v.y;
+                                    se += v.z;
+                                    sa += v.w;
+                                }
+                            }
+                        }
+                        if (ovf) {
+                            prod = pr;
+                            sge = se;
+                            sga = sa;
+                        }
+                    }
+                    alpha[o] = 1.0f - prod;
+                    if (GRAD) {
+                        // d alpha/d theta = -(A/sigma) * sum_k p_k d(d_k)/d theta   
+                        const float coef = -prod * kInvSigma;
+                        dae[o] = coef * sge;
+                        daa[o] = coef * sga;
+                    }
+                }
+            }
+
+            // ---- per-pixel epilogue -------------------------------------------------------
+            const size_t pix = (size_t)yi * S + xi;
+            if (SOFT) {
+                // environment.py:373: image = i1*i2 + i2*i3 + i1*i3 ; RGB of every silhouette is 1
+                const float I = alpha[0] * alpha[1] + alpha[1] * alpha[2] + alpha[0] * alpha[2];
+                float l = I * I, ge = 0.f, ga = 0.f;
+                if (GRAD) {
+                    const float g0 = alpha[1] + alpha[2], g1 = alpha[0] + alpha[2], g2 = alpha[0] + alpha[1];
+                    ge = 2.0f * I * (g0 * dae[0] + g1 * dae[1] + g2 * dae[2]);
+                    ga = 2.0f * I * (g0 * daa[0] + g1 * daa[1] + g2 * daa[2]);
+                }
+                l = wave_sum(l);
+                if (GRAD) {
+                    ge = wave_sum(ge);
+                    ga = wave_sum(ga);
+                }
+                if (lane == 0) {
+                    reinterpret_cast<float4*>(P.ws.partials)[item] = make_float4(l, ge, ga, 0.f);
+                }
+                if (P.out.full_state) {
+                    reinterpret_cast<float4*>(P.out.full_state)[(size_t)env * S * S + pix] = make_float4(3.f, 3.f, 3.f, I);
+                }
+                if (P.out.alphas) {
+                    float* __restrict__ al = P.out.alphas + (size_t)env * 3 * S * S + pix;
+                    al[0] = alpha[0];
+                    al[(size_t)S * S] = alpha[1];
+                    al[(size_t)2 * S * S] = alpha[2];
+                }
+                if (__ballot(list_ovf) && lane == 0) atomicOr(&P.ws.status[env], OCC_STATUS_LIST_OVERFLOW);
+            }
+            if (HARD) {
+                // [P3D] HardFlatShader + hard_rgb_blend; depth in channel 3 (environment.py:378)
+                float cr = 1.f, cg = 1.f, cb = 1.f, depth = -1.f;
+                if (hrec >= 0) {
+                    const int o = hrec / cap, j = hrec - o * cap;
+                    const int eo = env * 3 + o;
+                    const float* __restrict__ r = P.ws.rec + ((size_t)eo * cap + j) * OCC_REC_STRIDE;
+                    const int fid = __float_as_int(r[R_ID]);
+                    const int mesh = P.sc.scene_mesh[eo];
+                    const int vo = P.sc.mesh_vert_off[mesh], fo = P.sc.mesh_face_off[mesh];
+                    const float ox = P.sc.scene_offset[eo * 3], oy = P.sc.scene_offset[eo * 3 + 1],
+                                oz = P.sc.scene_offset[eo * 3 + 2];
+                    float w[3][3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int vi = P.sc.pool_faces[(size_t)(fo + fid) * 3 + k];
+                        const float* pv = P.sc.pool_verts + (size_t)(vo + vi) * 3;
+                        w[k][0] = pv[0] + ox;
+                        w[k][1] = pv[1] + oy;
+                        w[k][2] = pv[2] + oz;
+                    }
+                    const float ax = w[1][0] - w[0][0], ay = w[1][1] - w[0][1], az = w[1][2] - w[0][2];
+                    const float bx = w[2][0] - w[0][0], by = w[2][1] - w[0][1], bz = w[2][2] - w[0][2];
+                    float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+                    float nn = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), kShadeEps);
+                    nx /= nn; ny /= nn; nz /= nn;
+                    nn = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), kShadeEps);  // F.normalize again in diffuse()/specular()
+                    nx /= nn; ny /= nn; nz /= nn;
+                    const float ccx = (w[0][0] + w[1][0] + w[2][0]) / 3.0f, ccy = (w[0][1] + w[1][1] + w[2][1]) / 3.0f,
+                                ccz = (w[0][2] + w[1][2] + w[2][2]) / 3.0f;
+                    float lx = kLightX - ccx, ly = kLightY - ccy, lz = kLightZ - ccz;
+                    const float ln = fmaxf(sqrtf(lx * lx + ly * ly + lz * lz), kShadeEps);
+                    lx /= ln; ly /= ln; lz /= ln;
+                    const float cosang = nx * lx + ny * ly + nz * lz;
+                    const float diffuse = kDiffuse * fmaxf(cosang, 0.f);
+                    const float* __restrict__ cm = P.cam + (size_t)env * OCC_CAM_STRIDE;
+                    float vx = cm[C_C] - ccx, vy = cm[C_C + 1] - ccy, vz = cm[C_C + 2] - ccz;
+                    const float vn = fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), kShadeEps);
+                    vx /= vn; vy /= vn; vz /= vn;
+                    const float rx = -lx + 2.f * (cosang * nx), ry = -ly + 2.f * (cosang * ny), rz = -lz + 2.f * (cosang * nz);
+                    float sa = fmaxf(vx * rx + vy * ry + vz * rz, 0.f) * (cosang > 0.f ? 1.f : 0.f);
+                    sa *= sa; sa *= sa; sa *= sa; sa *= sa; sa *= sa; sa *= sa;  // ^64
+                    const float spec = kSpecular * sa;
+                    // texel: white TexturesVertex interpolated with the (unclipped) barycentrics
+                    const float x0 = r[R_X0], y0 = r[R_Y0], z0 = r[R_Z0], x1 = r[R_X1], y1 = r[R_Y1], z1 = r[R_Z1];
+                    const float x2 = r[R_X2], y2 = r[R_Y2], z2 = r[R_Z2];
+                    const float ia = r[R_INV_AREA];
+                    const float b0 = ((xf - x1) * (y2 - y1) - (yf - y1) * (x2 - x1)) * ia;
+                    const float b1 = ((yf - y2) * (x2 - x0) - (xf - x2) * (y2 - y0)) * ia;
+                    const float b2 = ((xf - x0) * (y1 - y0) - (yf - y0) * (x1 - x0)) * ia;
+                    const float w0 = b0 * z1 * z2, w1 = z0 * b1 * z2, w2 = z0 * z1 * b2;
+                    const float den = fmaxf(w0 + w1 + w2, kEpsilon);
+                    const float texel = w0 / den + w1 / den + w2 / den;
+                    const float col = (kAmbient + diffuse) * texel + spec;
+                    cr = cg = cb = col;
+                    depth = hz;
+                }
+                float* __restrict__ ob = P.out.obs + (size_t)env * 4 * S * S + pix;
+                ob[0] = cr;
+                ob[(size_t)S * S] = cg;
+                ob[(size_t)2 * S * S] = cb;
+                ob[(size_t)3 * S * S] = depth;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-env fixed-order reduction of the tile partials
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void occ_reduce_kernel(const float* __restrict__ partials, int ntiles,
+                                                        float* __restrict__ loss, float* __restrict__ grad_elaz) {
+    const int env = blockIdx.x, lane = threadIdx.x;
+    const float4* __restrict__ p = reinterpret_cast<const float4*>(partials) + (size_t)env * ntiles;
+    float l = 0.f, ge = 0.f, ga = 0.f;
+    for (int t = lane; t < ntiles; t += 64) {
+        const float4 v = p[t];
+        l += v.x;
+        ge += v.y;
+        ga += v.z;
+    }
+    l = wave_sum(l);
+    ge = wave_sum(ge);
+    ga = wave_sum(ga);
+    if (lane == 0) {
+        if (loss) loss[env] = l;
+        if (grad_elaz) {
+            grad_elaz[2 * env] = ge;
+            grad_elaz[2 * env + 1] = ga;
+        }
+    }
+}
+
+// environment.py:381-392 + action Jacobian (:356-361)
+__global__ __launch_bounds__(64) void occ_finish_kernel(const float* __restrict__ loss, const float* __restrict__ grad_elaz,
+                                                        const float* __restrict__ cam, float* __restrict__ full_reward,
+                                                        const float* __restrict__ object_mass, float* __restrict__ reward,
+                                                        uint8_t* __restrict__ done, float* __restrict__ grad_action,
+                                                        int n_env) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_env) return;
+    const float l = loss[n];
+    const float om = object_mass[n];
+    float rw = full_reward[n] - l;
+    full_reward[n] = l;
+    const bool fin = l < kDoneThreshold;
+    rw = rw / om;
+    rw = fin ? rw + kDoneBonus : rw - kStepPenalty;
+    reward[n] = rw;
+    done[n] = fin ? 1 : 0;
+    if (grad_action) {
+        float ga0 = 0.f, ga1 = 0.f;
+        if (grad_elaz) {
+            const float* __restrict__ J = cam + (size_t)n * OCC_CAM_STRIDE + C_J;
+            const float gl_e = grad_elaz[2 * n], gl_a = grad_elaz[2 * n + 1];
+            // d reward/d action_j = -(1/objectMass) * (dL/del * del/da_j + dL/daz * daz/da_j)
+            ga0 = -(gl_e * J[0] + gl_a * J[2]) / om;
+            ga1 = -(gl_e * J[1] + gl_a * J[3]) / om;
+        }
+        grad_action[2 * n] = ga0;
+        grad_action[2 * n + 1] = ga1;
+    }
+}
+
+}  // namespace occ
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+using namespace occ;
+
+extern "C" int occ_abi_version(void) { return OCC_ABI_VERSION; }
+
+extern "C" int occ_device_cu_count(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    return prop.multiProcessorCount;
+}
+
+static bool scene_ok(const OccScene* s) {
+    return s && s->pool_verts && s->pool_faces && s->mesh_vert_off && s->mesh_face_off && s->scene_mesh &&
+           s->scene_offset && s->n_env > 0 && s->img >= OCC_TILE && s->img % OCC_TILE == 0 && s->img <= 2048 &&
+           s->rec_cap > 0;
+}
+
+extern "C" int occ_workspace_query(const OccScene* scene, int n_slots, OccWorkspaceSizes* out) {
+    if (!scene || !out || scene->n_env <= 0 || scene->img < OCC_TILE || scene->img % OCC_TILE || scene->rec_cap <= 0)
+        return OCC_ERR_ARG;
+    if (n_slots <= 0) {
+        const int cus = occ_device_cu_count();
+        n_slots = (cus > 0 ? cus : 256) * 8;
+    }
+    const size_t N = (size_t)scene->n_env, cap = (size_t)scene->rec_cap;
+    const size_t ntx = (size_t)scene->img / OCC_TILE;
+    out->rec_bytes = N * 3 * cap * OCC_REC_STRIDE * sizeof(float);
+    out->rec_bbox_bytes = N * 3 * cap * sizeof(uint32_t);
+    out->nrec_bytes = N * 3 * sizeof(int32_t);
+    out->objrect_bytes = N * 3 * 4 * sizeof(int32_t);
+    out->queue_bytes = 16 * sizeof(uint32_t);
+    out->lists_bytes = (size_t)n_slots * OCC_LIST_CAP * 64 * 4 * sizeof(float);
+    out->partials_bytes = N * ntx * ntx * 4 * sizeof(float);
+    out->status_bytes = N * sizeof(int32_t);
+    out->n_slots = n_slots;
+    return OCC_OK;
+}
+
+extern "C" int occ_camera(int mode, const float* action, float* el, float* az, const float* radius, float* cam,
+                          float* cam_pos_out, int n_env, void* stream) {
+    if (!cam || n_env <= 0) return OCC_ERR_ARG;
+    if (mode == OCC_CAM_STEP && (!action || !el || !az || !radius)) return OCC_ERR_ARG;
+    if (mode == OCC_CAM_LOOKAT && (!el || !az || !radius)) return OCC_ERR_ARG;
+    if (mode == OCC_CAM_POSITION && !action) return OCC_ERR_ARG;
+    if (mode < 0 || mode > 2) return OCC_ERR_ARG;
+    hipLaunchKernelGGL(occ_camera_kernel, dim3((n_env + 63) / 64), dim3(64), 0, (hipStream_t)stream, mode, action, el, az,
+                       radius, cam, cam_pos_out, n_env);
+    return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
+}
+
+extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWorkspace* ws, const OccRenderOut* out,
+                          int flags, int faces_per_pixel, void* stream) {
+    if (!scene_ok(scene) || !cam || !ws || !out) return OCC_ERR_ARG;
+    if (!ws->rec || !ws->rec_bbox || !ws->nrec || !ws->objrect || !ws->queue || !ws->lists || !ws->partials ||
+        !ws->status || ws->n_slots <= 0)
+        return OCC_ERR_ARG;
+    const bool soft = flags & OCC_RENDER_SOFT, hard = flags & OCC_RENDER_HARD, grad = flags & OCC_RENDER_GRAD;
+    if (!soft && !hard) return OCC_ERR_ARG;
+    if (grad && !soft) return OCC_ERR_ARG;
+    if (hard && !out->obs) return OCC_ERR_ARG;
+    if (soft && (faces_per_pixel <= 0 || faces_per_pixel > OCC_MAX_K)) return OCC_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(ws->queue, 0, 16 * sizeof(uint32_t), st) != hipSuccess) return OCC_ERR_LAUNCH;
+    const int N = scene->n_env;
+    if (grad)
+        hipLaunchKernelGGL(occ_setup_kernel<true>, dim3(N * 3), dim3(256), 0, st, *scene, cam, *ws);
+    else
+        hipLaunchKernelGGL(occ_setup_kernel<false>, dim3(N * 3), dim3(256), 0, st, *scene, cam, *ws);
+    if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
+    TileParams P;
+    P.sc = *scene;
+    P.ws = *ws;
+    P.out = *out;
+    P.cam = cam;
+    P.K = faces_per_pixel;
+    P.ntx = scene->img / OCC_TILE;
+    const dim3 grid(ws->n_slots), block(64);
+    if (soft && hard && grad)
+        hipLaunchKernelGGL((occ_tile_kernel<true, true, true>), grid, block, 0, st, P);
+    else if (soft && hard)
+        hipLaunchKernelGGL((occ_tile_kernel<true, true, false>), grid, block, 0, st, P);
+    else if (soft && grad)
+        hipLaunchKernelGGL((occ_tile_kernel<true, false, true>), grid, block, 0, st, P);
+    else if (soft)
+        hipLaunchKernelGGL((occ_tile_kernel<true, false, false>), grid, block, 0, st, P);
+    else
+        hipLaunchKernelGGL((occ_tile_kernel<false, true, false>), grid, block, 0, st, P);
+    if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
+    if (soft && (out->loss || out->grad_elaz)) {
+        hipLaunchKernelGGL(occ_reduce_kernel, dim3(N), dim3(64), 0, st, ws->partials, P.ntx * P.ntx, out->loss,
+                           grad ? out->grad_elaz : nullptr);
+        if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
+    }
+    return OCC_OK;
+}
+
+extern "C" int occ_step_finish(const float* loss, const float* grad_elaz, const float* cam, float* full_reward,
+                               const float* object_mass, float* reward, uint8_t* done, float* grad_action, int n_env,
+                               void* stream) {
+    if (!loss || !cam || !full_reward || !object_mass || !reward || !done || n_env <= 0) return OCC_ERR_ARG;
+    hipLaunchKernelGGL(occ_finish_kernel, dim3((n_env + 63) / 64), dim3(64), 0, (hipStream_t)stream, loss, grad_elaz, cam,
+                       full_reward, object_mass, reward, done, grad_action, n_env);
+    return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
+}

@@ -1,0 +1,249 @@
+"""Batched in-process engine: N environments' meshes and cameras packed into ONE launch sequence
+(camera -> setup -> tile raster -> reduce -> finish) on one GPU.
+
+It replaces the sequential per-env Python loop of ``SimpleVecEnv.step_wait``
+(/root/reference/SubProcVecEnv.py:209-218) and the four PyTorch3D renders + autograd graph of
+``OcclusionEnv.step`` (/root/reference/environment.py:352-396).  All arithmetic happens in the HIP
+kernels behind the C ABI (include/occlusionenv_amd.h); torch is used for device memory, streams and
+the autograd hook only.  No CPU fallback exists: constructing an engine without the HIP extension
+or without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+from . import _native as nat
+from .meshes import MeshPool
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class _RewardGrad(torch.autograd.Function):
+    """Attaches d reward / d action (computed in forward mode by the render sweep) to autograd, so
+    ``reward.backward()`` / ``rewards.sum().backward()`` fill ``action.grad`` like the reference
+    (demo.py:86, train_predict.py:52)."""
+
+    @staticmethod
+    def forward(ctx, actions, reward, grad_action):
+        ctx.save_for_backward(grad_action)
+        return reward.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad_action,) = ctx.saved_tensors
+        return g.reshape(-1, 1) * grad_action, None, None
+
+
+class OcclusionEngine:
+    """State + workspace of N environments on one GPU."""
+
+    def __init__(self, pool: MeshPool, n_env: int, img_size: int, device=None, faces_per_pixel: int = 100,
+                 waves_per_cu: Optional[int] = None):
+        self.lib = nat.load()
+        if not torch.cuda.is_available():
+            raise nat.NativeError("OcclusionEngine needs a ROCm GPU (torch.cuda.is_available() is False); "
+                                  "there is no CPU fallback")
+        if img_size % nat.TILE or img_size < nat.TILE or img_size > 2048:
+            raise ValueError(f"img_size must be a multiple of {nat.TILE} in [8, 2048]")
+        if not (0 < faces_per_pixel <= nat.MAX_K):
+            raise ValueError(f"faces_per_pixel must be in 1..{nat.MAX_K}")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.pool = pool
+        self.N = int(n_env)
+        self.S = int(img_size)
+        self.K = int(faces_per_pixel)
+        self.waves_per_cu = int(waves_per_cu or os.environ.get("OCC_WAVES_PER_CU", 12))
+        d = self.device
+        f32 = dict(dtype=torch.float32, device=d)
+        N = self.N
+        # environment state (environment.py:302-306,323-324)
+        self.elevation = torch.zeros(N, **f32)
+        self.azimuth = torch.zeros(N, **f32)
+        self.radius = torch.full((N,), 4.0, **f32)
+        self.camera_position = torch.zeros(N, 3, **f32)
+        self.full_reward = torch.zeros(N, **f32)
+        self.object_mass = torch.ones(N, **f32)
+        # scene description
+        self.scene_mesh = torch.zeros(N, 3, dtype=torch.int32, device=d)
+        self.scene_offset = torch.zeros(N, 3, 3, **f32)
+        # internal buffers
+        self.cam = torch.zeros(N, nat.CAM_STRIDE, **f32)
+        self.alphas = torch.zeros(N, 3, self.S, self.S, **f32)
+        self._ws_key = None
+        self._ws = None
+        self._ws_tensors = None
+
+    # ---- scenes ---------------------------------------------------------------------------
+    def set_scene(self, env_ids, mesh_ids, offsets) -> None:
+        """mesh_ids (n,3) pool ids of object 1..3, offsets (n,3,3) world offsets (environment.py:148,171)."""
+        idx = torch.as_tensor(env_ids, dtype=torch.long, device=self.device).reshape(-1)
+        m = torch.as_tensor(mesh_ids, dtype=torch.int32).reshape(-1, 3)
+        if int(m.min()) < 0 or int(m.max()) >= len(self.pool):
+            raise ValueError("mesh id outside the pool")
+        self.scene_mesh[idx] = m.to(self.device)
+        self.scene_offset[idx] = torch.as_tensor(offsets, dtype=torch.float32).reshape(-1, 3, 3).to(self.device)
+
+    # ---- workspace ------------------------------------------------------------------------
+    def _scene_struct(self, n, scene_mesh, scene_offset) -> nat.OccScene:
+        pv, pf, vo, fo = self.pool.device_tensors()
+        sc = nat.OccScene()
+        sc.pool_verts, sc.pool_faces = pv.data_ptr(), pf.data_ptr()
+        sc.mesh_vert_off, sc.mesh_face_off = vo.data_ptr(), fo.data_ptr()
+        sc.scene_mesh, sc.scene_offset = scene_mesh.data_ptr(), scene_offset.data_ptr()
+        sc.n_meshes, sc.n_env, sc.img = len(self.pool), n, self.S
+        sc.rec_cap = self._rec_cap()
+        return sc
+
+    def _rec_cap(self) -> int:
+        # a z-clipped face can split in two: worst case 2 records per face
+        return 2 * max(self.pool.max_faces, 1)
+
+    def _ensure_workspace(self) -> nat.OccWorkspace:
+        key = (self._rec_cap(), self.N, self.S)
+        if self._ws_key == key:
+            return self._ws
+        sc = self._scene_struct(self.N, self.scene_mesh, self.scene_offset)
+        sizes = nat.OccWorkspaceSizes()
+        cus = self.lib.occ_device_cu_count()
+        if cus <= 0:
+            raise nat.NativeError("occ_device_cu_count failed")
+        n_slots = cus * self.waves_per_cu
+        nat.check(self.lib.occ_workspace_query(C.byref(sc), n_slots, C.byref(sizes)), "occ_workspace_query")
+        d = self.device
+
+        def buf(nbytes):
+            return torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=d)
+
+        t = dict(rec=buf(sizes.rec_bytes), rec_bbox=buf(sizes.rec_bbox_bytes), nrec=buf(sizes.nrec_bytes),
+                 objrect=buf(sizes.objrect_bytes), queue=buf(sizes.queue_bytes), lists=buf(sizes.lists_bytes),
+                 partials=buf(sizes.partials_bytes), status=buf(sizes.status_bytes))
+        ws = nat.OccWorkspace()
+        for k, v in t.items():
+            setattr(ws, k, v.data_ptr())
+        ws.n_slots = sizes.n_slots
+        self._ws, self._ws_tensors, self._ws_key = ws, t, key
+        return ws
+
+    @property
+    def status(self) -> torch.Tensor:
+        self._ensure_workspace()
+        return self._ws_tensors["status"][: self.N]
+
+    def check_status(self) -> None:
+        """Raise if any kernel reported a data-dependent failure (host sync)."""
+        st = int(self.status.max().item())
+        if st:
+            bad = torch.nonzero(self.status).reshape(-1)[:8].tolist()
+            self.status.zero_()
+            raise nat.NativeError(
+                f"kernel status {st} for envs {bad}: "
+                f"{'a pixel exceeded OCC_LIST_CAP soft candidates; ' if st & nat.STATUS_LIST_OVERFLOW else ''}"
+                f"{'face-record capacity exceeded' if st & nat.STATUS_REC_OVERFLOW else ''}")
+
+    # ---- launches -------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _render(self, idx: Optional[torch.Tensor], cam_mode: int, cam_input: Optional[torch.Tensor], flags: int):
+        """Camera + render for all envs (idx None) or the compact subset idx.  Returns a dict of fresh tensors."""
+        ws = self._ensure_workspace()
+        d, S = self.device, self.S
+        f32 = dict(dtype=torch.float32, device=d)
+        if idx is None:
+            n = self.N
+            el, az, rad = self.elevation, self.azimuth, self.radius
+            cam, campos, alphas = self.cam, self.camera_position, self.alphas
+            smesh, soff = self.scene_mesh, self.scene_offset
+        else:
+            n = int(idx.numel())
+            el, az, rad = self.elevation[idx], self.azimuth[idx], self.radius[idx]
+            cam = torch.empty(n, nat.CAM_STRIDE, **f32)
+            campos = torch.empty(n, 3, **f32)
+            alphas = torch.empty(n, 3, S, S, **f32)
+            smesh, soff = self.scene_mesh[idx].contiguous(), self.scene_offset[idx].contiguous()
+        st = self._stream()
+        cam_in = None if cam_input is None else cam_input.contiguous()
+        # reset() leaves camera_position untouched (environment.py:302 zeros, never written by reset)
+        write_pos = campos if cam_mode == nat.CAM_STEP else None
+        nat.check(self.lib.occ_camera(cam_mode, _p(cam_in), _p(el), _p(az), _p(rad), _p(cam), _p(write_pos), n, st),
+                  "occ_camera")
+        out = {}
+        ro = nat.OccRenderOut()
+        if flags & nat.RENDER_HARD:
+            out["obs"] = torch.empty(n, 4, S, S, **f32)
+            ro.obs = out["obs"].data_ptr()
+        if flags & nat.RENDER_SOFT:
+            out["full_state"] = torch.empty(n, S, S, 4, **f32)
+            out["loss"] = torch.empty(n, **f32)
+            ro.full_state, ro.loss, ro.alphas = out["full_state"].data_ptr(), out["loss"].data_ptr(), alphas.data_ptr()
+        if flags & nat.RENDER_GRAD:
+            out["grad_elaz"] = torch.empty(n, 2, **f32)
+            ro.grad_elaz = out["grad_elaz"].data_ptr()
+        sc = self._scene_struct(n, smesh, soff)
+        nat.check(self.lib.occ_render(C.byref(sc), _p(cam), C.byref(ws), C.byref(ro), flags, self.K, st), "occ_render")
+        if idx is not None:
+            if cam_mode == nat.CAM_STEP:
+                self.elevation[idx], self.azimuth[idx] = el, az
+                self.camera_position[idx] = campos
+            self.cam[idx] = cam
+            if flags & nat.RENDER_SOFT:
+                self.alphas[idx] = alphas
+        out["cam"] = cam
+        out["_keep"] = (smesh, soff, el, az, rad, cam_in)  # keep temporaries alive until the stream is done with them
+        return out
+
+    def reset_render(self, env_ids=None, radius=4.0, azimuth=0.0, elevation=0.0):
+        """State init + initial renders of reset() (environment.py:302-324).  Returns (obs, loss) for the subset."""
+        idx = None if env_ids is None else torch.as_tensor(env_ids, dtype=torch.long, device=self.device).reshape(-1)
+        sel = slice(None) if idx is None else idx
+
+        def put(dst, val):
+            dst[sel] = torch.as_tensor(val, dtype=torch.float32, device=self.device) if not torch.is_tensor(val) \
+                else val.to(self.device, torch.float32)
+
+        put(self.radius, radius)
+        put(self.elevation, elevation)
+        put(self.azimuth, azimuth)
+        self.camera_position[sel] = 0.0
+        out = self._render(idx, nat.CAM_LOOKAT, None, nat.RENDER_SOFT | nat.RENDER_HARD)
+        loss = out["loss"]
+        self.full_reward[sel] = loss
+        self.object_mass[sel] = loss + 1.0  # normWithObjectSize=False (environment.py:208,324)
+        return out["obs"], loss, out["full_state"]
+
+    def render_hard(self, env_ids=None):
+        """render() (environment.py:332-347): hard RGB-D at the current camera_position."""
+        idx = None if env_ids is None else torch.as_tensor(env_ids, dtype=torch.long, device=self.device).reshape(-1)
+        pos = self.camera_position if idx is None else self.camera_position[idx]
+        out = self._render(idx, nat.CAM_POSITION, pos, nat.RENDER_HARD)
+        return out["obs"]
+
+    def step(self, actions: torch.Tensor, env_ids=None):
+        """Batched step(): returns (obs (n,4,S,S), reward (n,) [autograd-attached], done (n,) bool, full_state, loss)."""
+        idx = None if env_ids is None else torch.as_tensor(env_ids, dtype=torch.long, device=self.device).reshape(-1)
+        n = self.N if idx is None else int(idx.numel())
+        if actions.shape != (n, 2):
+            raise ValueError(f"actions must have shape ({n}, 2), got {tuple(actions.shape)}")
+        need_grad = bool(actions.requires_grad and torch.is_grad_enabled())
+        a = actions.detach().to(self.device, torch.float32).contiguous()
+        flags = nat.RENDER_SOFT | nat.RENDER_HARD | (nat.RENDER_GRAD if need_grad else 0)
+        out = self._render(idx, nat.CAM_STEP, a, flags)
+        d = self.device
+        reward = torch.empty(n, dtype=torch.float32, device=d)
+        done = torch.empty(n, dtype=torch.uint8, device=d)
+        grad_action = torch.empty(n, 2, dtype=torch.float32, device=d) if need_grad else None
+        fr = self.full_reward if idx is None else self.full_reward[idx]
+        om = self.object_mass if idx is None else self.object_mass[idx]
+        nat.check(self.lib.occ_step_finish(_p(out["loss"]), _p(out.get("grad_elaz")), _p(out["cam"]), _p(fr), _p(om),
+                                           _p(reward), _p(done), _p(grad_action), n, self._stream()), "occ_step_finish")
+        if idx is not None:
+            self.full_reward[idx] = fr
+        if need_grad:
+            reward = _RewardGrad.apply(actions, reward, grad_action)
+        return out["obs"], reward, done.bool(), out["full_state"], out["loss"]

@@ -1,0 +1,232 @@
+"""Mesh sources for the OcclusionEnv hot path: OBJ reader, procedural ShapeNet-sized meshes,
+and the GPU-resident packed mesh pool the kernels index.
+
+Reference behaviour mirrored here:
+  * ``load_obj("./data/teapot.obj")`` verts / faces.verts_idx (/root/reference/environment.py:56-57);
+    the teapot file uses ``f a//na b//nb c//nc`` records.
+  * the ShapeNetCore duck-type consumed by ``load_shapenet_meshes`` (environment.py:106-135):
+    ``synset_dict``, ``synset_inv``, ``synset_start_idxs``, ``synset_num_models`` and
+    ``dataset[i] -> {"verts","faces","textures","synset_id","label","model_id"}``.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def default_teapot_path() -> str:
+    """``./data/teapot.obj`` like the reference (environment.py:56), else the packaged data fixture."""
+    for p in ("./data/teapot.obj", os.path.join(_HERE, "..", "data", "teapot.obj"),
+              os.path.join(_HERE, "..", "tests", "golden", "teapot.obj")):
+        if os.path.exists(p):
+            return os.path.abspath(p)
+    raise FileNotFoundError("teapot.obj not found (looked in ./data and tests/golden)")
+
+
+def load_obj(path: str) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Minimal Wavefront reader: returns (verts (V,3) f32, faces (F,3) int64, 0-based).
+    Handles ``v``, ``f a``, ``f a/b``, ``f a//c``, ``f a/b/c``, negative indices; polygons are fan-triangulated."""
+    verts: List[List[float]] = []
+    faces: List[List[int]] = []
+    with open(path, "r") as fh:
+        for line in fh:
+            if line.startswith("v "):
+                p = line.split()
+                verts.append([float(p[1]), float(p[2]), float(p[3])])
+            elif line.startswith("f "):
+                idx = []
+                for tok in line.split()[1:]:
+                    i = int(tok.split("/")[0])
+                    idx.append(i - 1 if i > 0 else len(verts) + i)
+                for k in range(1, len(idx) - 1):
+                    faces.append([idx[0], idx[k], idx[k + 1]])
+    return torch.tensor(verts, dtype=torch.float32), torch.tensor(faces, dtype=torch.int64)
+
+
+# ---- procedural meshes (SURVEY.md §8d "ShapeNet-size synthetic pool") -------------------------
+def icosphere(subdiv: int = 4) -> Tuple[np.ndarray, np.ndarray]:
+    """Unit icosphere; subdiv=4 -> V=2562, F=5120."""
+    t = (1.0 + math.sqrt(5.0)) / 2.0
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], dtype=np.float64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    f = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2],
+                  [10, 7, 6], [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5],
+                  [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]], dtype=np.int64)
+    verts = [tuple(x) for x in v]
+    for _ in range(subdiv):
+        cache: Dict[Tuple[int, int], int] = {}
+        nf = []
+
+        def mid(a, b):
+            key = (a, b) if a < b else (b, a)
+            if key not in cache:
+                m = (np.array(verts[a]) + np.array(verts[b])) / 2.0
+                m /= np.linalg.norm(m)
+                cache[key] = len(verts)
+                verts.append(tuple(m))
+            return cache[key]
+
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [[a, ab, ca], [b, bc, ab], [c, ca, bc], [ab, bc, ca]]
+        f = np.array(nf, dtype=np.int64)
+    return np.array(verts, dtype=np.float64), f
+
+
+def torus(nu: int = 64, nv: int = 40, R: float = 1.0, r: float = 0.4) -> Tuple[np.ndarray, np.ndarray]:
+    """Torus; 64x40 -> V=2560, F=5120."""
+    u = np.linspace(0, 2 * np.pi, nu, endpoint=False)
+    v = np.linspace(0, 2 * np.pi, nv, endpoint=False)
+    uu, vv = np.meshgrid(u, v, indexing="ij")
+    x = (R + r * np.cos(vv)) * np.cos(uu)
+    y = (R + r * np.cos(vv)) * np.sin(uu)
+    z = r * np.sin(vv)
+    verts = np.stack([x, y, z], -1).reshape(-1, 3)
+    faces = []
+    for i in range(nu):
+        for j in range(nv):
+            a = i * nv + j
+            b = ((i + 1) % nu) * nv + j
+            c = ((i + 1) % nu) * nv + (j + 1) % nv
+            d = i * nv + (j + 1) % nv
+            faces += [[a, b, c], [a, c, d]]
+    return verts, np.array(faces, dtype=np.int64)
+
+
+def _orient_outward(verts: np.ndarray, faces: np.ndarray) -> np.ndarray:
+    """Flip the winding if the signed volume is negative (PyTorch3D culls by screen-space winding)."""
+    a, b, c = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+    vol = np.einsum("ij,ij->i", a, np.cross(b, c)).sum()
+    return faces if vol > 0 else faces[:, ::-1].copy()
+
+
+def _normalise(verts: np.ndarray) -> np.ndarray:
+    """Centre and scale to unit bounding-box diagonal (ShapeNet convention)."""
+    lo, hi = verts.min(0), verts.max(0)
+    verts = verts - (lo + hi) / 2.0
+    return verts / np.linalg.norm(hi - lo)
+
+
+def synthetic_mesh(rng: np.random.Generator, faces_level: int = 5120) -> Tuple[torch.Tensor, torch.Tensor]:
+    """One seeded watertight mesh: icosphere or torus with smooth radial noise and anisotropic scale.
+    faces_level in {1280, 5120, 20480}."""
+    kind = rng.integers(0, 2)
+    if kind == 0 or faces_level != 5120:
+        sub = {1280: 3, 5120: 4, 20480: 5}[faces_level]
+        v, f = icosphere(sub)
+        # smooth radial noise from a few random low-order lobes
+        k = rng.normal(size=(4, 3))
+        amp = 0.1 * rng.normal(size=4)
+        rad = 1.0 + sum(a * np.sin(2.0 * v @ kk) for a, kk in zip(amp, k))
+        v = v * rad[:, None]
+    else:
+        v, f = torus(64, 40, 1.0, float(rng.uniform(0.25, 0.5)))
+    v = v * rng.uniform(0.4, 1.0, size=3)[None, :]
+    # random rotation
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                   [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    v = _normalise(v @ Rm.T)
+    f = _orient_outward(v, f)
+    return torch.tensor(v, dtype=torch.float32), torch.tensor(f, dtype=torch.int64)
+
+
+class SyntheticShapeNet:
+    """In-memory stand-in with the ShapeNetCore duck-type ``load_shapenet_meshes`` consumes
+    (environment.py:106-135).  ``mixed=True`` draws face counts {1280, 5120, 20480} with weights
+    {0.25, 0.6, 0.15}; otherwise every mesh has 5120 faces (the headline workload)."""
+
+    def __init__(self, n_models: int = 64, seed: int = 1234, mixed: bool = False, n_categories: int = 4):
+        rng = np.random.default_rng(seed)
+        self.models: List[Tuple[torch.Tensor, torch.Tensor]] = []
+        for _ in range(n_models):
+            level = int(rng.choice([1280, 5120, 20480], p=[0.25, 0.6, 0.15])) if mixed else 5120
+            self.models.append(synthetic_mesh(rng, level))
+        n_categories = max(1, min(n_categories, n_models))
+        per = n_models // n_categories
+        self.synset_dict = {f"{i:08d}": f"synthetic_{i}" for i in range(n_categories)}
+        self.synset_inv = {v: k for k, v in self.synset_dict.items()}
+        self.synset_start_idxs = {k: i * per for i, k in enumerate(self.synset_dict)}
+        self.synset_num_models = {k: (per if i < n_categories - 1 else n_models - per * (n_categories - 1))
+                                  for i, k in enumerate(self.synset_dict)}
+
+    def __len__(self):
+        return len(self.models)
+
+    def __getitem__(self, idx):
+        idx = int(idx)
+        v, f = self.models[idx]
+        cat = max(k for k, s in self.synset_start_idxs.items() if s <= idx)
+        return {"verts": v, "faces": f, "textures": None, "synset_id": cat, "label": self.synset_dict[cat],
+                "model_id": f"model_{idx:05d}"}
+
+
+class MeshPool:
+    """Packed, GPU-resident pool: ``verts (sumV,3) f32``, ``faces (sumF,3) i32`` (vertex ids local to the mesh),
+    ``vert_off (M+1) i32``, ``face_off (M+1) i32``.  Meshes can be appended; the packed tensors are
+    re-uploaded lazily (``device_tensors``)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self._verts: List[torch.Tensor] = []
+        self._faces: List[torch.Tensor] = []
+        self._keys: Dict[object, int] = {}
+        self._packed = None
+        self.version = 0
+
+    def __len__(self):
+        return len(self._verts)
+
+    @property
+    def max_faces(self) -> int:
+        return max((int(f.shape[0]) for f in self._faces), default=0)
+
+    def num_faces(self, mesh_id: int) -> int:
+        return int(self._faces[mesh_id].shape[0])
+
+    def add(self, verts: torch.Tensor, faces: torch.Tensor, key=None) -> int:
+        if key is not None and key in self._keys:
+            return self._keys[key]
+        verts = torch.as_tensor(verts, dtype=torch.float32).detach().cpu().contiguous()
+        faces = torch.as_tensor(faces).detach().cpu().to(torch.int32).contiguous()
+        if verts.ndim != 2 or verts.shape[1] != 3 or faces.ndim != 2 or faces.shape[1] != 3:
+            raise ValueError("verts must be (V,3) and faces (F,3)")
+        if faces.numel() and (int(faces.min()) < 0 or int(faces.max()) >= verts.shape[0]):
+            raise ValueError("face index out of range")
+        self._verts.append(verts)
+        self._faces.append(faces)
+        mid = len(self._verts) - 1
+        if key is not None:
+            self._keys[key] = mid
+        self._packed = None
+        self.version += 1
+        return mid
+
+    def get(self, mesh_id: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self._verts[mesh_id], self._faces[mesh_id].long()
+
+    def device_tensors(self):
+        if self._packed is None:
+            if not self._verts:
+                raise ValueError("empty mesh pool")
+            voff = np.zeros(len(self._verts) + 1, dtype=np.int32)
+            foff = np.zeros(len(self._verts) + 1, dtype=np.int32)
+            voff[1:] = np.cumsum([v.shape[0] for v in self._verts])
+            foff[1:] = np.cumsum([f.shape[0] for f in self._faces])
+            self._packed = (
+                torch.cat(self._verts).to(self.device),
+                torch.cat(self._faces).to(self.device),
+                torch.from_numpy(voff).to(self.device),
+                torch.from_numpy(foff).to(self.device),
+            )
+        return self._packed
