@@ -43,14 +43,16 @@ extern "C" {
 #define OCC_ERR_LAUNCH 2 /* hipLaunch failed (hipGetLastError != success) */
 
 /* per-env status bits written by the kernels (0 = fine) */
-#define OCC_STATUS_LIST_OVERFLOW 1 /* a pixel had more soft candidates than OCC_LIST_CAP */
+#define OCC_STATUS_LIST_OVERFLOW 1 /* reserved (lists are compacted exactly, never dropped) */
 #define OCC_STATUS_REC_OVERFLOW 2  /* more visible (clipped) faces than record capacity */
 
 /* layout constants shared with the host */
 #define OCC_CAM_STRIDE 48  /* floats per env in the camera buffer */
 #define OCC_REC_STRIDE 40  /* floats per projected-face record */
 #define OCC_TILE 8         /* pixels per tile side: one wave64 owns an 8x8 tile */
-#define OCC_LIST_CAP 512   /* soft candidates kept per pixel before OCC_STATUS_LIST_OVERFLOW */
+#ifndef OCC_LIST_CAP
+#define OCC_LIST_CAP 512   /* per-pixel candidate list capacity; a full list is compacted in place to its K nearest */
+#endif
 #define OCC_MAX_K 128      /* largest faces_per_pixel the fused path accepts */
 
 /* occ_camera modes */
@@ -84,7 +86,7 @@ typedef struct OccWorkspace {
     int32_t* nrec;      /* (n_env,3) */
     int32_t* objrect;   /* (n_env,3,4) tile rect tx0,ty0,tx1,ty1 (inclusive) */
     uint32_t* queue;    /* (16) work-queue head (zeroed by occ_render) */
-    float* lists;       /* (n_slots,OCC_LIST_CAP,64,4) per-wave candidate lists */
+    float* lists;       /* (n_slots,OCC_LIST_CAP,64,4) f32 payload rows, then (n_slots,OCC_LIST_CAP,64) u32 key rows */
     float* partials;    /* (n_env,ntiles,4) per-tile loss / gradient partial sums */
     int32_t* status;    /* (n_env) OCC_STATUS_* bits, OR-ed in; caller clears */
     int32_t n_slots;    /* persistent waves = blocks the tile kernel is launched with */
@@ -137,6 +139,16 @@ int occ_render(const OccScene* scene, const float* cam, const OccWorkspace* ws,
 int occ_step_finish(const float* loss, const float* grad_elaz, const float* cam,
                     float* full_reward, const float* object_mass, float* reward, uint8_t* done,
                     float* grad_action, int n_env, void* stream);
+
+/*
+ * Measurement hooks (bench.py only; not part of the reference surface).  While enabled, occ_render
+ * brackets its dominant kernel (occ_tile_kernel) with HIP events on the launch stream.
+ * occ_profile_read synchronises the recorded events (host sync!), returns the summed duration in
+ * milliseconds and the number of launches since the last read -- counting only the launches with the
+ * largest n_env seen (full batches; auto-resets render tiny ones) -- and resets the ring (max 4096 launches).
+ */
+int occ_profile_enable(int on);
+int occ_profile_read(double* ms_sum, int* launches);
 
 #ifdef __cplusplus
 }

@@ -133,34 +133,45 @@ class SimpleVecEnv(VecEnv):
         if bool(flags[1]):
             eng.check_status()
         if bool(flags[0]):
-            for i in torch.nonzero(dones).reshape(-1).tolist():
-                # save final observation where user can get it, then reset (SubProcVecEnv.py:211-214)
-                infos.set(i, "terminal_observation", obs[i:i + 1].clone())
-                obs[i] = self.envs[i].reset()[0]
+            # save final observation where user can get it, then reset (SubProcVecEnv.py:211-214); all
+            # finished envs are reset together (one batched render per rejection round)
+            fin = torch.nonzero(dones).reshape(-1)
+            term = obs[fin].clone()
+            fin_l = fin.tolist()
+            for j, i in enumerate(fin_l):
+                infos.set(i, "terminal_observation", term[j:j + 1])
+            obs[fin] = self._reset_envs(fin_l, torch.zeros(len(fin_l)))[:, 0]
         return obs, rewards, dones, infos
 
     def seed(self, seed=None):
         return [env.seed(seed + idx) for idx, env in enumerate(self.envs)]
 
-    def reset(self):
+    def _reset_envs(self, indices, az):
+        """reset() of the listed envs, batched: every rejection round (environment.py:288-327, at most 10)
+        draws new scenes for the still-pending envs on the host and renders them in ONE launch sequence."""
         eng, N = self.engine, self.num_envs
-        az = torch.tensor([np.random.default_rng().uniform(low=-40, high=40) for _ in range(N)], dtype=torch.float32)
-        pending = list(range(N))
-        obs_all = torch.empty(N, 1, 4, eng.S, eng.S, dtype=torch.float32, device=eng.device)
-        for rnd in range(1, 11):  # max_resets = 10 (environment.py:288)
+        az = torch.as_tensor(az, dtype=torch.float32)
+        pos = {i: j for j, i in enumerate(indices)}
+        pending = list(indices)
+        obs_all = torch.empty(len(indices), 1, 4, eng.S, eng.S, dtype=torch.float32, device=eng.device)
+        for rnd in range(1, 11):
+            scenes = []
             for i in pending:
                 tries = 0
-                while not self.envs[i]._new_scene():
+                while not self.envs[i]._new_scene(upload=False):
                     tries += 1
                     if tries >= 1000:
                         raise RuntimeError("reset(): could not load a scene")
+                scenes.append(self.envs[i]._scene)
+            eng.set_scene(pending, [sc[0] for sc in scenes], [sc[1] for sc in scenes])
             ids = None if len(pending) == N else pending
-            obs, loss, full_state = eng.reset_render(ids, 4.0, az if ids is None else az[pending], 0.0)
+            sel = torch.tensor([pos[i] for i in pending])
+            obs, loss, full_state = eng.reset_render(ids, 4.0, az[sel], 0.0)
             eng.check_status()
             ok = (loss > 0.1).cpu().tolist()
+            obs_all[sel.to(eng.device), 0] = obs
             keep = []
             for j, i in enumerate(pending):
-                obs_all[i, 0] = obs[j]
                 self.envs[i].image = full_state[j:j + 1]
                 if not ok[j] and rnd < 10:
                     keep.append(i)
@@ -168,6 +179,10 @@ class SimpleVecEnv(VecEnv):
             if not pending:
                 break
         return obs_all
+
+    def reset(self):
+        az = [np.random.default_rng().uniform(low=-40, high=40) for _ in range(self.num_envs)]
+        return self._reset_envs(list(range(self.num_envs)), az)
 
     def close(self):
         for env in self.envs:

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libocc_hip.so")
+# OCC_HIP_LIB selects another build of the SAME sources (tests use a small-OCC_LIST_CAP build); never a fallback
+LIB_PATH = os.environ.get("OCC_HIP_LIB") or os.path.join(_HERE, "libocc_hip.so")
 
 # layout constants (must match include/occlusionenv_amd.h)
 ABI_VERSION = 1
@@ -89,6 +90,8 @@ SYMBOLS = {
     "occ_render": (C.c_int, [C.POINTER(OccScene), C.c_void_p, C.POINTER(OccWorkspace), C.POINTER(OccRenderOut),
                              C.c_int, C.c_int, C.c_void_p]),
     "occ_step_finish": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_void_p]),
+    "occ_profile_enable": (C.c_int, [C.c_int]),
+    "occ_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
 
 

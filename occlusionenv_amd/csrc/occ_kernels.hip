@@ -574,6 +574,92 @@ __device__ __forceinline__ uint32_t zkey(float z) {
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+// Exact top-K-by-z over one lane's candidate list (entries e = 0..cnt-1, in face order; key row e at
+// keys[e*64 + lane], payload (z, 1-p, g_el, g_az) at list[e*64 + lane]).  Keeps the K smallest
+// (z, then earlier entry) like [P3D]'s (pz, face) ordering.
+//
+// The list lives in HBM/L2 (it does not fit LDS at 12 waves/CU), so the selection is organised to touch it
+// as little as possible: a most-significant-digit radix select, 6 bits per level, whose per-lane 64-bucket
+// histogram sits in LDS (u16 counters, lane stride 33 dwords = conflict-free when lanes agree).  Each level
+// is one coalesced sweep over the 4-byte key rows; the window [L, L + 64<<sh) starts at the lane's own
+// [kmin, kmax] range, so two levels resolve 12 bits below the first differing bit - typically enough.
+// The last sweep reads the payload rows once and takes every key below the boundary bucket plus the first
+// `need` keys inside it (all of it unless keys tie exactly).  Lanes with active == false idle.
+// COMPACT: also moves the kept entries to the front of the list (stable) for the in-loop overflow case.
+template <bool COMPACT>
+__device__ __forceinline__ void topk_select(float4* __restrict__ list, uint32_t* __restrict__ keys,
+                                            uint32_t* __restrict__ hist, int lane, int cnt, int K, bool active,
+                                            uint32_t kmin, uint32_t kmax, float& pr, float& se, float& sa,
+                                            uint32_t& Tmax) {
+    const int maxc = wave_max_i(active ? cnt : 0);
+    uint32_t* __restrict__ h = hist + lane * 33;
+    uint32_t L = kmin;
+    const uint32_t range = kmax - kmin;
+    int sh = range ? max(0, (32 - __builtin_clz(range)) - 6) : 0;
+    int need = K;
+    bool done = !active;
+    while (__ballot(!done)) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) h[i] = 0u;
+        for (int e = 0; e < maxc; ++e) {
+            if (!done && e < cnt) {
+                const uint32_t k = keys[(size_t)e * 64 + lane];
+                const uint32_t d = (k - L) >> sh;
+                if (k >= L && d < 64u) h[d >> 1] += 1u << (16 * (d & 1u));
+            }
+        }
+        int cum = 0, bstar = 63, mstar = 0, cumb = 0;
+        bool found = false;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const uint32_t w = h[i];
+            const int c0 = (int)(w & 0xFFFFu), c1 = (int)(w >> 16);
+            if (!found && cum + c0 >= need) { found = true; bstar = 2 * i; mstar = c0; cumb = cum; }
+            cum += c0;
+            if (!found && cum + c1 >= need) { found = true; bstar = 2 * i + 1; mstar = c1; cumb = cum; }
+            cum += c1;
+        }
+        if (!done) {
+            need -= cumb;
+            L += (uint32_t)bstar << sh;
+            if (mstar == need || sh == 0 || !found) {
+                done = true;
+            } else {
+                sh = max(0, sh - 6);
+            }
+        }
+    }
+    // final sweep: keys below L, then the first `need` keys of the boundary bucket [L, L + 2^sh)
+    int take = need, w = 0;
+    pr = 1.0f;
+    se = 0.f;
+    sa = 0.f;
+    uint32_t tmax = 0;
+    for (int e = 0; e < maxc; ++e) {
+        if (active && e < cnt) {
+            const uint32_t k = keys[(size_t)e * 64 + lane];
+            bool inc = k < L;
+            if (k >= L && ((k - L) >> sh) == 0u && take > 0) {
+                inc = true;
+                take -= 1;
+            }
+            if (inc) {
+                const float4 v = list[(size_t)e * 64 + lane];
+                pr *= v.y;
+                se += v.z;
+                sa += v.w;
+                tmax = max(tmax, k);
+                if (COMPACT) {
+                    list[(size_t)w * 64 + lane] = v;
+                    keys[(size_t)w * 64 + lane] = k;
+                    w += 1;
+                }
+            }
+        }
+    }
+    Tmax = tmax;
+}
+
 struct TileParams {
     OccScene sc;
     OccWorkspace ws;
@@ -583,7 +669,7 @@ struct TileParams {
     int ntx;  // tiles per image side
 };
 
-constexpr int kChunk = 4;  // tiles dequeued per atomic
+constexpr int kChunkMax = 4;  // tiles dequeued per atomic (fewer when the batch is small)
 
 template <bool SOFT, bool HARD, bool GRAD>
 __global__ __launch_bounds__(64) void occ_tile_kernel(TileParams P) {
@@ -591,10 +677,16 @@ __global__ __launch_bounds__(64) void occ_tile_kernel(TileParams P) {
     const int S = P.sc.img;
     const int ntx = P.ntx, ntiles = ntx * ntx;
     const int total_items = P.sc.n_env * ntiles;
+    // per-wave K-buffer: payload rows (float4) for every slot first, then the compact key rows
     float4* __restrict__ mylist = reinterpret_cast<float4*>(P.ws.lists) + (size_t)blockIdx.x * OCC_LIST_CAP * 64;
+    uint32_t* __restrict__ mykeys = reinterpret_cast<uint32_t*>(reinterpret_cast<float4*>(P.ws.lists) +
+                                                                (size_t)gridDim.x * OCC_LIST_CAP * 64) +
+                                    (size_t)blockIdx.x * OCC_LIST_CAP * 64;
+    __shared__ uint32_t s_hist[64 * 33];
     const float fS = (float)S;
     const int cap = P.sc.rec_cap;
     const int K = P.K;
+    const int kChunk = max(1, min(kChunkMax, total_items / ((int)gridDim.x * 8)));
 
     for (;;) {
         int start = 0;
@@ -614,7 +706,6 @@ __global__ __launch_bounds__(64) void occ_tile_kernel(TileParams P) {
             float dae[3] = {0.f, 0.f, 0.f}, daa[3] = {0.f, 0.f, 0.f};
             float hz = 3.0e38f;
             int hrec = -1;  // (object * cap + record) of the nearest hard face
-            bool list_ovf = false;
 
 #pragma unroll 1
             for (int o = 0; o < 3; ++o) {
@@ -628,13 +719,31 @@ __global__ __launch_bounds__(64) void occ_tile_kernel(TileParams P) {
                 float prod = 1.0f, sge = 0.f, sga = 0.f;
                 bool skip0 = false;
 
+                bool thr_on = false;   // set once this lane's list has been compacted to its K nearest
+                uint32_t thrT = 0;     // key of the K-th nearest so far: later candidates need key < thrT
+                uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;  // key range of the stored candidates
                 auto commit = [&](bool cnd, float z, float q, float ge, float ga) {
-                    if (cnd) {
-                        if (count < OCC_LIST_CAP) {
-                            mylist[(size_t)count * 64 + lane] = make_float4(z, q, ge, ga);
-                        } else {
-                            list_ovf = true;
+                    const uint32_t key = zkey(z);
+                    bool acc = cnd && (!thr_on || key < thrT);
+                    if (__ballot(acc && count >= OCC_LIST_CAP)) {
+                        // rare: a pixel collected OCC_LIST_CAP candidates -> keep its K nearest, go on
+                        const bool full = count >= OCC_LIST_CAP;
+                        float pr, se, sa;
+                        uint32_t T;
+                        topk_select<true>(mylist, mykeys, s_hist, lane, count, K, full, kmin, kmax, pr, se, sa, T);
+                        if (full) {
+                            count = K;
+                            thr_on = true;
+                            thrT = T;
+                            kmax = T;
+                            acc = cnd && (key < thrT);
                         }
+                    }
+                    if (acc) {
+                        mylist[(size_t)count * 64 + lane] = make_float4(z, q, ge, ga);
+                        mykeys[(size_t)count * 64 + lane] = key;
+                        kmin = min(kmin, key);
+                        kmax = max(kmax, key);
                         count += 1;
                         prod *= q;
                         sge += ge;
@@ -693,59 +802,20 @@ __global__ __launch_bounds__(64) void occ_tile_kernel(TileParams P) {
                             Cand c2;
                             eval_face<SOFT, GRAD>(r + OCC_REC_STRIDE, xf, yf, c2);
                             hard_update(c2, j + 1);
-                            if (SOFT) {
-                                const bool take2 = c2.cand && (!c1.cand || c2.ad < c1.ad);
-                                const bool any = c1.cand || c2.cand;
-                                commit(any, take2 ? c2.z : c1.z, take2 ? c2.q : c1.q, take2 ? c2.ge : c1.ge,
-                                       take2 ? c2.ga : c1.ga);
-                            }
-                        } else if (SOFT) {
-                            commit(c1.cand, c1.z, c1.q, c1.ge, c1.ga);
+                            const bool take2 = c2.cand && (!c1.cand || c2.ad < c1.ad);
+                            if (take2) c1 = c2;
                         }
+                        if (SOFT) commit(c1.cand, c1.z, c1.q, c1.ge, c1.ga);
                     }
                 }
 
                 if (SOFT) {
                     // more than K candidates: keep the K nearest in z (ties: earlier face first), SURVEY A.4
-                    const bool ovf = count > K;
+                    const bool ovf = (count > K) || thr_on;
                     if (__ballot(ovf)) {
-                        const int cnt = min(count, OCC_LIST_CAP);
-                        const int maxc = wave_max_i(ovf ? cnt : 0);
-                        uint32_t T = 0;
-                        for (int bitp = 31; bitp >= 0; --bitp) {
-                            const uint32_t candT = T | (1u << bitp);
-                            int cless = 0;
-                            for (int e = 0; e < maxc; ++e) {
-                                if (ovf && e < cnt) {
-                                    const float z = mylist[(size_t)e * 64 + lane].x;
-                                    cless += (zkey(z) < candT) ? 1 : 0;
-                                }
-                            }
-                            if (cless < K) T = candT;
-                        }
-                        // T = K-th smallest key.  Take all below, then the first (K - nless) equal ones.
-                        int nless = 0;
-                        for (int e = 0; e < maxc; ++e) {
-                            if (ovf && e < cnt) nless += (zkey(mylist[(size_t)e * 64 + lane].x) < T) ? 1 : 0;
-                        }
-                        int take = K - nless;
-                        float pr = 1.0f, se = 0.f, sa = 0.f;
-                        for (int e = 0; e < maxc; ++e) {
-                            if (ovf && e < cnt) {
-                                const float4 v = mylist[(size_t)e * 64 + lane];
-                                const uint32_t k = zkey(v.x);
-                                bool inc = k < T;
-                                if (k == T && take > 0) {
-                                    inc = true;
-                                    take -= 1;
-                                }
-                                if (inc) {
-                                    pr *= v.y;
-                                    se += v.z;
-                                    sa += v.w;
-                                }
-                            }
-                        }
+                        float pr, se, sa;
+                        uint32_t T;
+                        topk_select<false>(mylist, mykeys, s_hist, lane, count, K, ovf, kmin, kmax, pr, se, sa, T);
                         if (ovf) {
                             prod = pr;
                             sge = se;
@@ -790,7 +860,6 @@ __global__ __launch_bounds__(64) void occ_tile_kernel(TileParams P) {
                     al[(size_t)S * S] = alpha[1];
                     al[(size_t)2 * S * S] = alpha[2];
                 }
-                if (__ballot(list_ovf) && lane == 0) atomicOr(&P.ws.status[env], OCC_STATUS_LIST_OVERFLOW);
             }
             if (HARD) {
                 // [P3D] HardFlatShader + hard_rgb_blend; depth in channel 3 (environment.py:378)
@@ -925,6 +994,46 @@ using namespace occ;
 
 extern "C" int occ_abi_version(void) { return OCC_ABI_VERSION; }
 
+// ---- measurement hooks ---------------------------------------------------------------------
+namespace {
+constexpr int kProfMax = 4096;
+bool g_prof_on = false;
+int g_prof_n = 0;
+hipEvent_t g_prof_ev[2 * kProfMax];
+int g_prof_nenv[kProfMax];
+bool g_prof_created = false;
+}  // namespace
+
+extern "C" int occ_profile_enable(int on) {
+    if (on && !g_prof_created) {
+        for (int i = 0; i < 2 * kProfMax; ++i)
+            if (hipEventCreate(&g_prof_ev[i]) != hipSuccess) return OCC_ERR_LAUNCH;
+        g_prof_created = true;
+    }
+    g_prof_on = on != 0;
+    g_prof_n = 0;
+    return OCC_OK;
+}
+
+extern "C" int occ_profile_read(double* ms_sum, int* launches) {
+    if (!ms_sum || !launches) return OCC_ERR_ARG;
+    double tot = 0.0;
+    int big = 0, cnt = 0;
+    for (int i = 0; i < g_prof_n; ++i) big = g_prof_nenv[i] > big ? g_prof_nenv[i] : big;
+    for (int i = 0; i < g_prof_n; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_prof_ev[2 * i + 1]) != hipSuccess) return OCC_ERR_LAUNCH;
+        if (hipEventElapsedTime(&ms, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]) != hipSuccess) return OCC_ERR_LAUNCH;
+        if (g_prof_nenv[i] != big) continue;  // full-batch launches only (auto-resets render tiny batches)
+        tot += ms;
+        cnt += 1;
+    }
+    *ms_sum = tot;
+    *launches = cnt;
+    g_prof_n = 0;
+    return OCC_OK;
+}
+
 extern "C" int occ_device_cu_count(void) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -953,7 +1062,7 @@ extern "C" int occ_workspace_query(const OccScene* scene, int n_slots, OccWorksp
     out->nrec_bytes = N * 3 * sizeof(int32_t);
     out->objrect_bytes = N * 3 * 4 * sizeof(int32_t);
     out->queue_bytes = 16 * sizeof(uint32_t);
-    out->lists_bytes = (size_t)n_slots * OCC_LIST_CAP * 64 * 4 * sizeof(float);
+    out->lists_bytes = (size_t)n_slots * OCC_LIST_CAP * 64 * (4 * sizeof(float) + sizeof(uint32_t));
     out->partials_bytes = N * ntx * ntx * 4 * sizeof(float);
     out->status_bytes = N * sizeof(int32_t);
     out->n_slots = n_slots;
@@ -999,6 +1108,8 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
     P.K = faces_per_pixel;
     P.ntx = scene->img / OCC_TILE;
     const dim3 grid(ws->n_slots), block(64);
+    const bool prof = g_prof_on && g_prof_n < kProfMax;
+    if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_n], st);
     if (soft && hard && grad)
         hipLaunchKernelGGL((occ_tile_kernel<true, true, true>), grid, block, 0, st, P);
     else if (soft && hard)
@@ -1009,6 +1120,11 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
         hipLaunchKernelGGL((occ_tile_kernel<true, false, false>), grid, block, 0, st, P);
     else
         hipLaunchKernelGGL((occ_tile_kernel<false, true, false>), grid, block, 0, st, P);
+    if (prof) {
+        (void)hipEventRecord(g_prof_ev[2 * g_prof_n + 1], st);
+        g_prof_nenv[g_prof_n] = N;
+        g_prof_n += 1;
+    }
     if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
     if (soft && (out->loss || out->grad_elaz)) {
         hipLaunchKernelGGL(occ_reduce_kernel, dim3(N), dim3(64), 0, st, ws->partials, P.ntx * P.ntx, out->loss,

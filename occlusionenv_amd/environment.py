@@ -189,7 +189,7 @@ class OcclusionEnv:
         counterpart because the tile kernel never drops faces."""
         self.faces_per_bin = max(mesh_size, 10000)
 
-    def _new_scene(self) -> bool:
+    def _new_scene(self, upload: bool = True) -> bool:
         eng = self._eng()
         try:
             ids, offs = sample_scene(self.shapenet_dataset, eng.pool)
@@ -198,7 +198,8 @@ class OcclusionEnv:
         if max(eng.pool.num_faces(m) for m in ids) > 250000:  # environment.py:296-298
             return False
         self._scene = (ids, offs)
-        eng.set_scene([self._slot], [ids], [offs])
+        if upload:
+            eng.set_scene([self._slot], [ids], [offs])
         self.createRenderers(max(eng.pool.num_faces(m) for m in ids) * 3)
         return True
 

@@ -1,0 +1,56 @@
+"""Rollout records and their exchange between the per-GPU env shards.
+
+Environments are independent (no cross-env term anywhere in /root/reference/environment.py:352-396), so the
+N-GPU design shards contiguous env ranges over ranks with no data-path collective; the only exchange is ONE
+all-gather per step of the small per-env rollout record the PPO learner consumes
+(/root/reference/PPO.py:157-162, trainRL.py:203-204):
+
+    256 f32 pooled features | 2 action | 1 logprob | 1 reward | 1 done   = 261 f32 = 1044 B / env-step
+
+``torch.distributed`` backend "nccl" is RCCL on ROCm; on the xGMI full mesh a 1 MB-per-rank all-gather is a
+latency-bound direct peer write.  Raw observations (262 KB/env) are never gathered.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+RECORD_FLOATS = 261
+
+
+def env_shard(n_total: int, rank: int, world: int):
+    """Contiguous env range of ``rank``: [rank*n/world, (rank+1)*n/world)."""
+    lo = (n_total * rank) // world
+    hi = (n_total * (rank + 1)) // world
+    return lo, hi
+
+
+def pooled_features(obs: torch.Tensor) -> torch.Tensor:
+    """Stand-in for the frozen encoder's 256-d pooled feature (PPO.py:155-157 takes FullNetwork features;
+    the network itself is out of scope): 4 channels x 8x8 adaptive average pool."""
+    return F.adaptive_avg_pool2d(obs, 8).reshape(obs.shape[0], 256)
+
+
+def pack_records(obs, actions, logprob, rewards, dones) -> torch.Tensor:
+    """(n,4,S,S), (n,2), (n,), (n,), (n,) -> (n, 261) f32."""
+    n = obs.shape[0]
+    rec = torch.empty(n, RECORD_FLOATS, dtype=torch.float32, device=obs.device)
+    rec[:, :256] = pooled_features(obs)
+    rec[:, 256:258] = actions.detach()
+    rec[:, 258] = logprob.detach()
+    rec[:, 259] = rewards.detach()
+    rec[:, 260] = dones.to(torch.float32)
+    return rec
+
+
+def all_gather_records(rec: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """One all-gather of the local (n,261) records -> (world*n, 261), rank-major (= global env order)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rec
+    world = dist.get_world_size()
+    if out is None:
+        out = torch.empty(world * rec.shape[0], rec.shape[1], dtype=rec.dtype, device=rec.device)
+    dist.all_gather_into_tensor(out, rec.contiguous())
+    return out
