@@ -107,7 +107,11 @@ def main():
     lib = nat.load()
     venv, ds = build_env(args.workload, args.envs, args.img, seed=42 + rank)
     eng = venv.engine
-    venv.reset()
+    # SURVEY.md §8d scene distribution: x2 ~ N(0,1) (np.random, seeded), az ~ U(-0.6, 0.6), el = 0; scenes pass
+    # the reference's reset rejection loop (loss > 0.1, environment.py:327).  VecEnv.reset() itself draws
+    # az ~ U(-40, 40) rad (SubProcVecEnv.py:233), which mostly yields non-occluding views that finish at once.
+    az0 = (torch.rand(args.envs, generator=torch.Generator().manual_seed(42 + rank)) * 2 - 1) * 0.6
+    venv._reset_envs(list(range(args.envs)), az0)
     dev = eng.device
     gen = torch.Generator(device=dev).manual_seed(7 + rank)
     gathered = torch.empty(world * args.envs, rollout.RECORD_FLOATS, device=dev) if world > 1 else None

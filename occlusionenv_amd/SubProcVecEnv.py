@@ -147,37 +147,59 @@ class SimpleVecEnv(VecEnv):
         return [env.seed(seed + idx) for idx, env in enumerate(self.envs)]
 
     def _reset_envs(self, indices, az):
-        """reset() of the listed envs, batched: every rejection round (environment.py:288-327, at most 10)
-        draws new scenes for the still-pending envs on the host and renders them in ONE launch sequence."""
+        """reset() of the listed envs, batched and speculative.  The reference retries scene draws one at a time
+        until the initial occlusion loss exceeds 0.1, at most 10 times, and keeps the 10th regardless
+        (environment.py:288-327).  Here every round draws several candidate scenes per pending env on the host
+        (in try order), renders ALL candidates in one launch sequence, and each env takes its first accepted
+        candidate -- the same outcome per env as trying them one by one, in far fewer GPU round trips."""
         eng, N = self.engine, self.num_envs
-        az = torch.as_tensor(az, dtype=torch.float32)
+        az = torch.as_tensor(az, dtype=torch.float32).reshape(-1)
         pos = {i: j for j, i in enumerate(indices)}
         pending = list(indices)
+        tries = {i: 0 for i in indices}
+        max_resets = 10
         obs_all = torch.empty(len(indices), 1, 4, eng.S, eng.S, dtype=torch.float32, device=eng.device)
-        for rnd in range(1, 11):
-            scenes = []
+        while pending:
+            per_env = max(1, min(4, N // len(pending)))
+            cand_env, cand_scene = [], []
             for i in pending:
-                tries = 0
-                while not self.envs[i]._new_scene(upload=False):
-                    tries += 1
-                    if tries >= 1000:
-                        raise RuntimeError("reset(): could not load a scene")
-                scenes.append(self.envs[i]._scene)
-            eng.set_scene(pending, [sc[0] for sc in scenes], [sc[1] for sc in scenes])
-            ids = None if len(pending) == N else pending
-            sel = torch.tensor([pos[i] for i in pending])
-            obs, loss, full_state = eng.reset_render(ids, 4.0, az[sel], 0.0)
+                for _ in range(min(per_env, max_resets - tries[i])):
+                    fails = 0
+                    while not self.envs[i]._new_scene(upload=False):
+                        fails += 1
+                        if fails >= 1000:
+                            raise RuntimeError("reset(): could not load a scene")
+                    cand_env.append(i)
+                    cand_scene.append(self.envs[i]._scene)
+            caz = az[torch.tensor([pos[i] for i in cand_env])]
+            res = eng.evaluate_scenes([sc[0] for sc in cand_scene], [sc[1] for sc in cand_scene], 4.0, caz, 0.0)
+            ok = (res["loss"] > 0.1).cpu().tolist()
             eng.check_status()
-            ok = (loss > 0.1).cpu().tolist()
-            obs_all[sel.to(eng.device), 0] = obs
-            keep = []
-            for j, i in enumerate(pending):
-                self.envs[i].image = full_state[j:j + 1]
-                if not ok[j] and rnd < 10:
-                    keep.append(i)
-            pending = keep
-            if not pending:
-                break
+            chosen_env, chosen_cand, still = [], [], []
+            k = 0
+            while k < len(cand_env):
+                i = cand_env[k]
+                pick = None
+                k0 = k
+                while k < len(cand_env) and cand_env[k] == i:
+                    tries_now = tries[i] + (k - k0) + 1
+                    if pick is None and (ok[k] or tries_now >= max_resets):
+                        pick = k
+                    k += 1
+                tries[i] += k - k0
+                if pick is None:
+                    still.append(i)
+                else:
+                    chosen_env.append(i)
+                    chosen_cand.append(pick)
+                    self.envs[i]._scene = cand_scene[pick]
+            if chosen_env:
+                eng.commit_reset(chosen_env, chosen_cand, res)
+                cc = torch.tensor(chosen_cand, device=eng.device)
+                obs_all[torch.tensor([pos[i] for i in chosen_env], device=eng.device), 0] = res["obs"][cc]
+                for i, c in zip(chosen_env, chosen_cand):
+                    self.envs[i].image = res["full_state"][c:c + 1]
+            pending = still
         return obs_all
 
     def reset(self):

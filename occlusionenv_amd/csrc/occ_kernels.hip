@@ -485,21 +485,34 @@ struct Cand {
 // Evaluate one projected face (wave-uniform record r -> SGPRs) at this lane's pixel centre.
 // Restates [P3D] CheckPixelInsideFace and, for GRAD, the dists part of
 // RasterizeMeshesBackward (A.5) pushed forward along the two vertex tangents.
+// One staged record pulled out of LDS with 16-byte broadcast reads (every lane reads the same address).
+// Slot map as in occ_constants.h:
+//   a = x0 y0 z0 x1 | b = y1 z1 x2 y2 | c = z2 id flags inv_area | d = bbox | e = il01 il02 il12 ile01 |
+//   f = ile02 ile12 - - | g, h, i = tangents of v0, v1, v2 (dx/del dy/del dx/daz dy/daz)
+// The nine float4 parts travel as SSA values (by value, never through a struct in memory: a select between two
+// loads of one stack object gets folded into a dynamically indexed load, which pins the object in scratch).
+#define OCC_REC_PARAMS float4 ra, float4 rb, float4 rc, float4 rd, float4 re, float4 rf, float4 rg, float4 rh, float4 ri
+#define OCC_REC_LOAD(src, PARTS)                                                                   \
+    (src)[0], (src)[1], (src)[2], (src)[3], ((PARTS) > 4 ? (src)[4] : make_float4(0, 0, 0, 0)),      \
+        ((PARTS) > 4 ? (src)[5] : make_float4(0, 0, 0, 0)), ((PARTS) > 6 ? (src)[6] : make_float4(0, 0, 0, 0)), \
+        ((PARTS) > 6 ? (src)[7] : make_float4(0, 0, 0, 0)), ((PARTS) > 6 ? (src)[8] : make_float4(0, 0, 0, 0))
+
+// Evaluate one projected face at this lane's pixel centre.
 template <bool SOFT, bool GRAD>
-__device__ __forceinline__ void eval_face(cfptr r, float xf, float yf, Cand& c) {
+__device__ __forceinline__ void eval_face(OCC_REC_PARAMS, float xf, float yf, Cand& c) {
     c.cand = false;
     c.inside = false;
     c.z = c.zh = c.ad = 0.f;
     c.q = 1.f;
     c.ge = c.ga = 0.f;
-    const bool inb = (r[R_BX0] <= xf) && (xf <= r[R_BX1]) && (r[R_BY0] <= yf) && (yf <= r[R_BY1]);
+    const bool inb = (rd.x <= xf) && (xf <= rd.y) && (rd.z <= yf) && (yf <= rd.w);
     if (!inb) return;
-    const float x0 = r[R_X0], y0 = r[R_Y0], z0 = r[R_Z0];
-    const float x1 = r[R_X1], y1 = r[R_Y1], z1 = r[R_Z1];
-    const float x2 = r[R_X2], y2 = r[R_Y2], z2 = r[R_Z2];
+    const float x0 = ra.x, y0 = ra.y, z0 = ra.z;
+    const float x1 = ra.w, y1 = rb.x, z1 = rb.y;
+    const float x2 = rb.z, y2 = rb.w, z2 = rc.x;
     const float dx0 = xf - x0, dy0 = yf - y0, dx1 = xf - x1, dy1 = yf - y1, dx2 = xf - x2, dy2 = yf - y2;
     const float ex01 = x1 - x0, ey01 = y1 - y0, ex02 = x2 - x0, ey02 = y2 - y0, ex12 = x2 - x1, ey12 = y2 - y1;
-    const float inv_area = r[R_INV_AREA];
+    const float inv_area = rc.w;
     // barycentrics: E(p;v1,v2), E(p;v2,v0), E(p;v0,v1) over area
     const float b0 = (dx1 * ey12 - dy1 * ex12) * inv_area;
     const float b1 = (dy2 * ex02 - dx2 * ey02) * inv_area;
@@ -520,7 +533,7 @@ __device__ __forceinline__ void eval_face(cfptr r, float xf, float yf, Cand& c) 
     c2 *= rs;
     const float pz = c0 * z0 + c1 * z1 + c2 * z2;
     // squared distance to the three edges (v0,v1), (v0,v2), (v1,v2)
-    const float il01 = r[R_IL01], il02 = r[R_IL02], il12 = r[R_IL12];
+    const float il01 = re.x, il02 = re.y, il12 = re.z;
     const float dot01 = ex01 * dx0 + ey01 * dy0;
     const float dot02 = ex02 * dx0 + ey02 * dy0;
     const float dot12 = ex12 * dx1 + ey12 * dy1;
@@ -551,15 +564,15 @@ __device__ __forceinline__ void eval_face(cfptr r, float xf, float yf, Cand& c) 
         const float bax = s01 ? ex01 : (s02 ? ex02 : ex12);
         const float bay = s01 ? ey01 : (s02 ? ey02 : ey12);
         const float dotv = s01 ? dot01 : (s02 ? dot02 : dot12);
-        const float ile = s01 ? r[R_ILE01] : (s02 ? r[R_ILE02] : r[R_ILE12]);
+        const float ile = s01 ? re.w : (s02 ? rf.x : rf.y);
         const float pax = s12 ? dx1 : dx0, pay = s12 ? dy1 : dy0;
         const float tb = clamp01(dotv * ile);
         const float gx = 2.0f * (tb * bax - pax), gy = 2.0f * (tb * bay - pay);  // 2 (proj - p)
         // tangent of the projected point: (1-t) a' + t b'
-        const float a_xe = s12 ? r[R_TAN + 4] : r[R_TAN + 0], a_ye = s12 ? r[R_TAN + 5] : r[R_TAN + 1];
-        const float a_xa = s12 ? r[R_TAN + 6] : r[R_TAN + 2], a_ya = s12 ? r[R_TAN + 7] : r[R_TAN + 3];
-        const float b_xe = s01 ? r[R_TAN + 4] : r[R_TAN + 8], b_ye = s01 ? r[R_TAN + 5] : r[R_TAN + 9];
-        const float b_xa = s01 ? r[R_TAN + 6] : r[R_TAN + 10], b_ya = s01 ? r[R_TAN + 7] : r[R_TAN + 11];
+        const float a_xe = s12 ? rh.x : rg.x, a_ye = s12 ? rh.y : rg.y;
+        const float a_xa = s12 ? rh.z : rg.z, a_ya = s12 ? rh.w : rg.w;
+        const float b_xe = s01 ? rh.x : ri.x, b_ye = s01 ? rh.y : ri.y;
+        const float b_xa = s01 ? rh.z : ri.z, b_ya = s01 ? rh.w : ri.w;
         const float mxe = a_xe + tb * (b_xe - a_xe), mye = a_ye + tb * (b_ye - a_ye);
         const float mxa = a_xa + tb * (b_xa - a_xa), mya = a_ya + tb * (b_ya - a_ya);
         const float any = (s01 || s02 || s12) ? 1.0f : 0.0f;
@@ -579,10 +592,10 @@ __device__ __forceinline__ uint32_t zkey(float z) {
 // (z, then earlier entry) like [P3D]'s (pz, face) ordering.
 //
 // The list lives in HBM/L2 (it does not fit LDS at 12 waves/CU), so the selection is organised to touch it
-// as little as possible: a most-significant-digit radix select, 6 bits per level, whose per-lane 64-bucket
-// histogram sits in LDS (u16 counters, lane stride 33 dwords = conflict-free when lanes agree).  Each level
-// is one coalesced sweep over the 4-byte key rows; the window [L, L + 64<<sh) starts at the lane's own
-// [kmin, kmax] range, so two levels resolve 12 bits below the first differing bit - typically enough.
+// as little as possible: a most-significant-digit radix select, 5 bits per level, whose per-lane 32-bucket
+// histogram sits in LDS (u16 counters, lane stride 17 dwords = conflict-free when lanes agree).  Each level
+// is one coalesced sweep over the 4-byte key rows; the window [L, L + 32<<sh) starts at the lane's own
+// [kmin, kmax] range, so two levels resolve 10 bits below the first differing bit - typically enough.
 // The last sweep reads the payload rows once and takes every key below the boundary bucket plus the first
 // `need` keys inside it (all of it unless keys tie exactly).  Lanes with active == false idle.
 // COMPACT: also moves the kept entries to the front of the list (stable) for the in-loop overflow case.
@@ -592,26 +605,37 @@ __device__ __forceinline__ void topk_select(float4* __restrict__ list, uint32_t*
                                             uint32_t kmin, uint32_t kmax, float& pr, float& se, float& sa,
                                             uint32_t& Tmax) {
     const int maxc = wave_max_i(active ? cnt : 0);
-    uint32_t* __restrict__ h = hist + lane * 33;
+    uint32_t* __restrict__ h = hist + lane * 17;
     uint32_t L = kmin;
     const uint32_t range = kmax - kmin;
-    int sh = range ? max(0, (32 - __builtin_clz(range)) - 6) : 0;
+    int sh = range ? max(0, (32 - __builtin_clz(range)) - 5) : 0;
     int need = K;
     bool done = !active;
     while (__ballot(!done)) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) h[i] = 0u;
-        for (int e = 0; e < maxc; ++e) {
-            if (!done && e < cnt) {
-                const uint32_t k = keys[(size_t)e * 64 + lane];
-                const uint32_t d = (k - L) >> sh;
-                if (k >= L && d < 64u) h[d >> 1] += 1u << (16 * (d & 1u));
+        for (int i = 0; i < 16; ++i) h[i] = 0u;
+        // key rows are swept 8 at a time: eight independent loads in flight per lane instead of one
+        for (int e0 = 0; e0 < maxc; e0 += 8) {
+            uint32_t kk[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = e0 + i;
+                kk[i] = (!done && e < cnt) ? keys[(size_t)e * 64 + lane] : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = e0 + i;
+                if (!done && e < cnt) {
+                    const uint32_t k = kk[i];
+                    const uint32_t d = (k - L) >> sh;
+                    if (k >= L && d < 32u) h[d >> 1] += 1u << (16 * (d & 1u));
+                }
             }
         }
-        int cum = 0, bstar = 63, mstar = 0, cumb = 0;
+        int cum = 0, bstar = 31, mstar = 0, cumb = 0;
         bool found = false;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
+        for (int i = 0; i < 16; ++i) {
             const uint32_t w = h[i];
             const int c0 = (int)(w & 0xFFFFu), c1 = (int)(w >> 16);
             if (!found && cum + c0 >= need) { found = true; bstar = 2 * i; mstar = c0; cumb = cum; }
@@ -625,7 +649,7 @@ __device__ __forceinline__ void topk_select(float4* __restrict__ list, uint32_t*
             if (mstar == need || sh == 0 || !found) {
                 done = true;
             } else {
-                sh = max(0, sh - 6);
+                sh = max(0, sh - 5);
             }
         }
     }
@@ -635,23 +659,41 @@ __device__ __forceinline__ void topk_select(float4* __restrict__ list, uint32_t*
     se = 0.f;
     sa = 0.f;
     uint32_t tmax = 0;
-    for (int e = 0; e < maxc; ++e) {
-        if (active && e < cnt) {
-            const uint32_t k = keys[(size_t)e * 64 + lane];
-            bool inc = k < L;
-            if (k >= L && ((k - L) >> sh) == 0u && take > 0) {
-                inc = true;
-                take -= 1;
+    for (int e0 = 0; e0 < maxc; e0 += 8) {
+        uint32_t kk[8];
+        bool inc[8];
+        float4 vv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = e0 + i;
+            kk[i] = (active && e < cnt) ? keys[(size_t)e * 64 + lane] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = e0 + i;
+            const uint32_t k = kk[i];
+            bool in_ = false;
+            if (active && e < cnt) {
+                in_ = k < L;
+                if (k >= L && ((k - L) >> sh) == 0u && take > 0) {
+                    in_ = true;
+                    take -= 1;
+                }
             }
-            if (inc) {
-                const float4 v = list[(size_t)e * 64 + lane];
-                pr *= v.y;
-                se += v.z;
-                sa += v.w;
-                tmax = max(tmax, k);
+            inc[i] = in_;
+            vv[i] = make_float4(0.f, 1.f, 0.f, 0.f);
+            if (in_) vv[i] = list[(size_t)e * 64 + lane];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (inc[i]) {
+                pr *= vv[i].y;
+                se += vv[i].z;
+                sa += vv[i].w;
+                tmax = max(tmax, kk[i]);
                 if (COMPACT) {
-                    list[(size_t)w * 64 + lane] = v;
-                    keys[(size_t)w * 64 + lane] = k;
+                    list[(size_t)w * 64 + lane] = vv[i];
+                    keys[(size_t)w * 64 + lane] = kk[i];
                     w += 1;
                 }
             }
@@ -682,15 +724,26 @@ __global__ __launch_bounds__(64) void occ_tile_kernel(TileParams P) {
     uint32_t* __restrict__ mykeys = reinterpret_cast<uint32_t*>(reinterpret_cast<float4*>(P.ws.lists) +
                                                                 (size_t)gridDim.x * OCC_LIST_CAP * 64) +
                                     (size_t)blockIdx.x * OCC_LIST_CAP * 64;
-    __shared__ uint32_t s_hist[64 * 33];
+    __shared__ uint32_t s_hist[64 * 17];
+    // face records of the current 64-face chunk that overlap this tile, staged by cooperative 16-B loads
+    // (one memory latency per chunk instead of one per face); slot 64 holds a clipped pair's partner that
+    // falls into the next chunk
+    constexpr int kParts = GRAD ? 9 : (SOFT ? 6 : 4);  // float4 parts of a record that this variant reads
+    __shared__ float4 s_stage[65 * 10];
+    __shared__ int s_hit[64];
     const float fS = (float)S;
     const int cap = P.sc.rec_cap;
     const int K = P.K;
-    const int kChunk = max(1, min(kChunkMax, total_items / ((int)gridDim.x * 8)));
 
+    // Two sweeps over the same (env, tile) item space, each with its own queue head: sweep 0 takes the tiles
+    // some object's rect covers (one tile per dequeue: they cost 0.1-1 ms each), sweep 1 the background tiles
+    // (16 per dequeue: they only write defaults).  The cheap items land at the end of the launch, so its tail
+    // is at most one heavy tile long instead of one chunk of heavy tiles.
+    for (int sweep = 0; sweep < 2; ++sweep) {
+    const int kChunk = sweep == 0 ? 1 : kChunkMax * 4;
     for (;;) {
         int start = 0;
-        if (lane == 0) start = (int)atomicAdd(P.ws.queue, (uint32_t)kChunk);
+        if (lane == 0) start = (int)atomicAdd(P.ws.queue + sweep, (uint32_t)kChunk);
         start = __builtin_amdgcn_readfirstlane(start);
         if (start >= total_items) break;
         const int stop = min(start + kChunk, total_items);
@@ -698,6 +751,14 @@ __global__ __launch_bounds__(64) void occ_tile_kernel(TileParams P) {
             const int env = item / ntiles;
             const int t = item - env * ntiles;
             const int ty = t / ntx, tx = t - ty * ntx;
+            {
+                ciptr rc = as_const(P.ws.objrect + env * 12);
+                bool occupied = false;
+#pragma unroll
+                for (int o = 0; o < 3; ++o)
+                    occupied |= !(tx < rc[4 * o] || ty < rc[4 * o + 1] || tx > rc[4 * o + 2] || ty > rc[4 * o + 3]);
+                if (occupied != (sweep == 0)) continue;
+            }
             const int xi = tx * OCC_TILE + (lane & 7), yi = ty * OCC_TILE + (lane >> 3);
             // [P3D] pixel centre in NDC, +X left, +Y up
             const float xf = -1.0f + (2.0f * (float)(S - 1 - xi) + 1.0f) / fS;
@@ -713,7 +774,7 @@ __global__ __launch_bounds__(64) void occ_tile_kernel(TileParams P) {
                 ciptr rect = as_const(P.ws.objrect + eo * 4);
                 if (tx < rect[0] || ty < rect[1] || tx > rect[2] || ty > rect[3]) continue;
                 const int n = as_const(P.ws.nrec + eo)[0];
-                cfptr recs = as_const(P.ws.rec + (size_t)eo * cap * OCC_REC_STRIDE);
+                const float* __restrict__ recs = P.ws.rec + (size_t)eo * cap * OCC_REC_STRIDE;
                 const uint32_t* __restrict__ bbs = P.ws.rec_bbox + (size_t)eo * cap;
                 int count = 0;
                 float prod = 1.0f, sge = 0.f, sga = 0.f;
@@ -740,8 +801,10 @@ __global__ __launch_bounds__(64) void occ_tile_kernel(TileParams P) {
                         }
                     }
                     if (acc) {
+#ifndef OCC_DBG_NO_STORE  // timing experiment only
                         mylist[(size_t)count * 64 + lane] = make_float4(z, q, ge, ga);
                         mykeys[(size_t)count * 64 + lane] = key;
+#endif
                         kmin = min(kmin, key);
                         kmax = max(kmax, key);
                         count += 1;
@@ -770,48 +833,67 @@ __global__ __launch_bounds__(64) void occ_tile_kernel(TileParams P) {
                         mask &= ~1ull;
                         skip0 = false;
                     }
-                    while (mask) {
-                        const int bit = __builtin_ctzll(mask);
-                        mask &= mask - 1;
-                        const int j = c0 + bit;
-                        cfptr r = recs + (size_t)j * OCC_REC_STRIDE;
-                        const int flags = __float_as_int(r[R_FLAGS]);
-                        Cand c1;
-                        eval_face<SOFT, GRAD>(r, xf, yf, c1);
-                        hard_update(c1, j);
-                        bool pair = false;
-                        if (flags & FLAG_PAIR_FIRST) {
-                            // clipped quad split in two: only the nearer-in-|d| of the pair
-                            // may enter a pixel's list
-                            bool second_hit;
-                            if (bit < 63) {
-                                second_hit = (mask >> (bit + 1)) & 1ull;
-                                if (second_hit) mask &= ~(1ull << (bit + 1));
-                            } else {
-                                second_hit = false;
-                                if (j + 1 < n) {
+                    if (mask) {
+                        const int nh = __popcll(mask);
+                        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+                        if (hit && ((mask >> lane) & 1ull)) s_hit[__popcll(mask & lt)] = lane;
+                        __syncthreads();
+                        for (int idx = lane; idx < nh * kParts; idx += 64) {
+                            const int k = idx / kParts, part = idx - k * kParts;
+                            const int j = c0 + s_hit[k];
+                            s_stage[k * 10 + part] = reinterpret_cast<const float4*>(recs + (size_t)j * OCC_REC_STRIDE)[part];
+                        }
+                        __syncthreads();
+                        for (int k = 0; k < nh; ++k) {
+                            const int bit = __builtin_amdgcn_readfirstlane(s_hit[k]);
+                            const int j = c0 + bit;
+                            const float4* rs = &s_stage[k * 10];
+                            const int flags = __builtin_amdgcn_readfirstlane(__float_as_int(rs[2].z));
+                            Cand c1;
+                            eval_face<SOFT, GRAD>(OCC_REC_LOAD(rs, kParts), xf, yf, c1);
+                            hard_update(c1, j);
+                            if (flags & FLAG_PAIR_FIRST) {
+                                // clipped quad split in two: only the nearer-in-|d| of the pair may
+                                // enter a pixel's list
+                                bool second_hit = false;
+                                const float4* r2 = &s_stage[(k + 1) * 10];
+                                if (bit < 63) {
+                                    second_hit = (k + 1 < nh) && (__builtin_amdgcn_readfirstlane(s_hit[k + 1]) == bit + 1);
+                                } else if (j + 1 < n) {
                                     const uint32_t b2 = bbs[j + 1];
                                     second_hit = ((int)(b2 & 0xFF) <= tx) && (tx <= (int)((b2 >> 16) & 0xFF)) &&
                                                  ((int)((b2 >> 8) & 0xFF) <= ty) && (ty <= (int)(b2 >> 24));
+                                    if (second_hit) {
+                                        skip0 = true;
+                                        if (lane < kParts)
+                                            s_stage[64 * 10 + lane] =
+                                                reinterpret_cast<const float4*>(recs + (size_t)(j + 1) * OCC_REC_STRIDE)[lane];
+                                        __syncthreads();
+                                        r2 = &s_stage[64 * 10];
+                                    }
                                 }
-                                if (second_hit) skip0 = true;
+                                if (second_hit) {
+                                    Cand c2;
+                                    eval_face<SOFT, GRAD>(OCC_REC_LOAD(r2, kParts), xf, yf, c2);
+                                    hard_update(c2, j + 1);
+                                    const bool take2 = c2.cand && (!c1.cand || c2.ad < c1.ad);
+                                    if (take2) c1 = c2;
+                                    if (bit < 63) k += 1;  // the partner was the next staged record: consumed
+                                }
                             }
-                            pair = second_hit;
+                            if (SOFT) commit(c1.cand, c1.z, c1.q, c1.ge, c1.ga);
                         }
-                        if (pair) {
-                            Cand c2;
-                            eval_face<SOFT, GRAD>(r + OCC_REC_STRIDE, xf, yf, c2);
-                            hard_update(c2, j + 1);
-                            const bool take2 = c2.cand && (!c1.cand || c2.ad < c1.ad);
-                            if (take2) c1 = c2;
-                        }
-                        if (SOFT) commit(c1.cand, c1.z, c1.q, c1.ge, c1.ga);
+                        __syncthreads();
                     }
                 }
 
                 if (SOFT) {
                     // more than K candidates: keep the K nearest in z (ties: earlier face first), SURVEY A.4
+#ifdef OCC_DBG_NO_TOPK  // timing experiment only: skip the exact selection (results wrong where count > K)
+                    const bool ovf = false;
+#else
                     const bool ovf = (count > K) || thr_on;
+#endif
                     if (__ballot(ovf)) {
                         float pr, se, sa;
                         uint32_t T;
@@ -925,6 +1007,7 @@ __global__ __launch_bounds__(64) void occ_tile_kernel(TileParams P) {
                 ob[(size_t)3 * S * S] = depth;
             }
         }
+    }
     }
 }
 

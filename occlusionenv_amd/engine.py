@@ -58,7 +58,7 @@ class OcclusionEngine:
         self.N = int(n_env)
         self.S = int(img_size)
         self.K = int(faces_per_pixel)
-        self.waves_per_cu = int(waves_per_cu or os.environ.get("OCC_WAVES_PER_CU", 12))
+        self.waves_per_cu = int(waves_per_cu or os.environ.get("OCC_WAVES_PER_CU", 10))
         d = self.device
         f32 = dict(dtype=torch.float32, device=d)
         N = self.N
@@ -216,6 +216,57 @@ class OcclusionEngine:
         self.full_reward[sel] = loss
         self.object_mass[sel] = loss + 1.0  # normWithObjectSize=False (environment.py:208,324)
         return out["obs"], loss, out["full_state"]
+
+    def evaluate_scenes(self, mesh_ids, offsets, radius, azimuth, elevation):
+        """Render m candidate scenes (NOT bound to env slots) with the reset() camera: the speculative half of
+        the batched reset.  m <= N (the workspace is sized for N envs).  Returns a dict of per-candidate tensors."""
+        d = self.device
+        f32 = dict(dtype=torch.float32, device=d)
+        smesh = torch.as_tensor(mesh_ids, dtype=torch.int32).reshape(-1, 3).to(d).contiguous()
+        m = smesh.shape[0]
+        if m > self.N:
+            raise ValueError("more candidate scenes than env slots")
+        if int(smesh.min()) < 0 or int(smesh.max()) >= len(self.pool):
+            raise ValueError("mesh id outside the pool")
+        soff = torch.as_tensor(offsets, dtype=torch.float32).reshape(m, 3, 3).to(d).contiguous()
+
+        def vec(v):
+            t = torch.as_tensor(v, dtype=torch.float32).to(d)
+            return t.expand(m).contiguous() if t.ndim == 0 else t.reshape(m).contiguous()
+
+        rad, az, el = vec(radius), vec(azimuth), vec(elevation)
+        ws = self._ensure_workspace()
+        S = self.S
+        cam = torch.empty(m, nat.CAM_STRIDE, **f32)
+        st = self._stream()
+        nat.check(self.lib.occ_camera(nat.CAM_LOOKAT, None, _p(el), _p(az), _p(rad), _p(cam), None, m, st), "occ_camera")
+        out = dict(obs=torch.empty(m, 4, S, S, **f32), full_state=torch.empty(m, S, S, 4, **f32),
+                   loss=torch.empty(m, **f32), alphas=torch.empty(m, 3, S, S, **f32), cam=cam,
+                   radius=rad, azimuth=az, elevation=el, scene_mesh=smesh, scene_offset=soff)
+        ro = nat.OccRenderOut()
+        ro.obs, ro.full_state, ro.loss, ro.alphas = (out["obs"].data_ptr(), out["full_state"].data_ptr(),
+                                                     out["loss"].data_ptr(), out["alphas"].data_ptr())
+        sc = self._scene_struct(m, smesh, soff)
+        nat.check(self.lib.occ_render(C.byref(sc), _p(cam), C.byref(ws), C.byref(ro), nat.RENDER_SOFT | nat.RENDER_HARD,
+                                      self.K, st), "occ_render")
+        return out
+
+    def commit_reset(self, env_ids, cand_ids, res) -> None:
+        """Install candidates ``cand_ids`` of an evaluate_scenes() result as the fresh state of ``env_ids``
+        (environment.py:302-306,323-324)."""
+        e = torch.as_tensor(env_ids, dtype=torch.long, device=self.device).reshape(-1)
+        c = torch.as_tensor(cand_ids, dtype=torch.long, device=self.device).reshape(-1)
+        self.scene_mesh[e] = res["scene_mesh"][c]
+        self.scene_offset[e] = res["scene_offset"][c]
+        self.radius[e] = res["radius"][c]
+        self.azimuth[e] = res["azimuth"][c]
+        self.elevation[e] = res["elevation"][c]
+        self.camera_position[e] = 0.0
+        self.cam[e] = res["cam"][c]
+        self.alphas[e] = res["alphas"][c]
+        loss = res["loss"][c]
+        self.full_reward[e] = loss
+        self.object_mass[e] = loss + 1.0
 
     def render_hard(self, env_ids=None):
         """render() (environment.py:332-347): hard RGB-D at the current camera_position."""
