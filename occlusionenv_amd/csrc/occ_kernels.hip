@@ -478,6 +478,7 @@ struct Cand {
     float z;      // soft depth (clipped barycentrics)
     float zh;     // hard depth (unclipped barycentrics)
     float ad;     // |squared distance|
+    int amin;     // closest edge: 0 = (v0,v1), 1 = (v0,v2), 2 = (v1,v2)
     float q;      // 1 - sigmoid(-d/sigma)
     float ge, ga; // p * d(d)/d el, p * d(d)/d az
 };
@@ -505,6 +506,7 @@ __device__ __forceinline__ void eval_face(OCC_REC_PARAMS, float xf, float yf, Ca
     c.z = c.zh = c.ad = 0.f;
     c.q = 1.f;
     c.ge = c.ga = 0.f;
+    c.amin = 0;
     const bool inb = (rd.x <= xf) && (xf <= rd.y) && (rd.z <= yf) && (yf <= rd.w);
     if (!inb) return;
     const float x0 = ra.x, y0 = ra.y, z0 = ra.z;
@@ -547,6 +549,11 @@ __device__ __forceinline__ void eval_face(OCC_REC_PARAMS, float xf, float yf, Ca
     const float d02 = qx02 * qx02 + qy02 * qy02;
     const float d12 = qx12 * qx12 + qy12 * qy12;
     const float dist = fmin3(d01, d02, d12);
+    // closest edge with [P3D] tie order e01, e02, e12
+    const bool s01 = (d01 <= d02) && (d01 <= d12);
+    const bool s02 = !s01 && (d02 <= d01) && (d02 <= d12);
+    const bool s12 = !s01 && !s02 && (d12 <= d01) && (d12 <= d02);
+    c.amin = s01 ? 0 : (s02 ? 1 : 2);
     const bool cand = !(pz < 0.0f) && (inside || dist < kBlurRadius);
     c.cand = cand;
     c.z = pz;
@@ -557,10 +564,7 @@ __device__ __forceinline__ void eval_face(OCC_REC_PARAMS, float xf, float yf, Ca
     const float p = frcp(1.0f + e);
     c.q = 1.0f - p;
     if (GRAD) {
-        // closest edge with [P3D] tie order e01, e02, e12; t recomputed with (l2 + eps) like the backward
-        const bool s01 = (d01 <= d02) && (d01 <= d12);
-        const bool s02 = !s01 && (d02 <= d01) && (d02 <= d12);
-        const bool s12 = !s01 && !s02 && (d12 <= d01) && (d12 <= d02);
+        // gradient through the closest edge; t recomputed with (l2 + eps) like [P3D]'s backward
         const float bax = s01 ? ex01 : (s02 ? ex02 : ex12);
         const float bay = s01 ? ey01 : (s02 ? ey02 : ey12);
         const float dotv = s01 ? dot01 : (s02 ? dot02 : dot12);
@@ -876,7 +880,11 @@ __global__ __launch_bounds__(64) void occ_tile_kernel(TileParams P) {
                                     Cand c2;
                                     eval_face<SOFT, GRAD>(OCC_REC_LOAD(r2, kParts), xf, yf, c2);
                                     hard_update(c2, j + 1);
-                                    const bool take2 = c2.cand && (!c1.cand || c2.ad < c1.ad);
+                                    // [P3D]: the second half replaces the first iff its |d| is strictly smaller.
+                                    // If both are closest to the diagonal they share (t1: edge (v1,v2), t2: edge
+                                    // (v0,v1)) the two distances are equal in exact arithmetic: keep the first.
+                                    const bool shared_tie = (c1.amin == 2) && (c2.amin == 0);
+                                    const bool take2 = c2.cand && (!c1.cand || (!shared_tie && c2.ad < c1.ad));
                                     if (take2) c1 = c2;
                                     if (bit < 63) k += 1;  // the partner was the next staged record: consumed
                                 }

@@ -90,10 +90,11 @@ static inline REAL point_line_dist(v2 p, v2 a, v2 b) {
     return dot2(d, d);
 }
 
-static inline REAL point_tri_dist(v2 p, v2 v0, v2 v1, v2 v2_) {
+static inline REAL point_tri_dist(v2 p, v2 v0, v2 v1, v2 v2_, int* amin) {
     const REAL e01 = point_line_dist(p, v0, v1);
     const REAL e02 = point_line_dist(p, v0, v2_);
     const REAL e12 = point_line_dist(p, v1, v2_);
+    *amin = (e01 <= e02 && e01 <= e12) ? 0 : ((e02 <= e01 && e02 <= e12) ? 1 : 2);
     return rmin(rmin(e01, e02), e12);
 }
 
@@ -114,6 +115,7 @@ static inline void point_line_dist_bwd(v2 p, v2 a, v2 b, REAL g, v2* ga, v2* gb)
 
 typedef struct {
     REAL z; int64_t f; REAL d; REAL b0, b1, b2;
+    int amin; /* closest edge: 0 = (v0,v1), 1 = (v0,v2), 2 = (v1,v2); not part of the ordering */
 } qent;
 
 /* lexicographic (z, f, d, b0, b1, b2) like std::tuple operator<  */
@@ -173,20 +175,29 @@ int FN(orc_rasterize_naive)(const REAL* face_verts, const int64_t* neighbor, int
                 const v3 bc = clip_barycentric ? bary_clip(b1) : b1;
                 const REAL pz = bc.x * z0 + bc.y * z1 + bc.z * z2;
                 if (pz < 0) continue;
-                const REAL dist = point_tri_dist(pxy, v0, v1, v2_);
+                int amin;
+                const REAL dist = point_tri_dist(pxy, v0, v1, v2_, &amin);
                 const int inside = b1.x > 0 && b1.y > 0 && b1.z > 0;
                 const REAL sdist = inside ? -dist : dist;
                 if (!inside && dist >= blur_radius) continue;
 
-                const qent e = {pz, f, sdist, bc.x, bc.y, bc.z};
+                const qent e = {pz, f, sdist, bc.x, bc.y, bc.z, amin};
                 int idx_top = -1;
                 const int64_t nb = neighbor ? neighbor[f] : -1;
                 if (nb != -1) {
                     for (int i = 0; i < qn; ++i) if (q[i].f == nb) { idx_top = i; break; }
                 }
                 if (idx_top != -1) {
+                    /* Upstream: "if (dist < neighbor_dist) overwrite".  When the closest edge of BOTH halves is
+                     * the diagonal they share -- t1 = (p4,p2,p5): edge (v1,v2); t2 = (p5,p2,p3): edge (v0,v1),
+                     * SURVEY A.3 -- the two distances are the same number in exact arithmetic and the strict '<'
+                     * keeps the first half; in floating point the outcome is rounding noise (upstream's CPU and
+                     * CUDA paths disagree with each other there).  This restatement fixes that case to the
+                     * exact-arithmetic answer (keep the first half) so that it is well defined. */
+                    const int shared_tie = (nb == f - 1 && q[idx_top].amin == 2 && amin == 0) ||
+                                           (nb == f + 1 && q[idx_top].amin == 0 && amin == 2);
                     const REAL dn = (REAL)fabs((double)q[idx_top].d);
-                    if (dist < dn) q[idx_top] = e;
+                    if (!shared_tie && dist < dn) q[idx_top] = e;
                 } else {
                     q[qn++] = e;
                 }

@@ -49,13 +49,13 @@ def oracle_env(case, i, img):
     return O.OracleEnv(objs, img)
 
 
-def run_engine(case, img, n_env=None, faces_per_pixel=100):
+def run_engine(case, img, n_env=None, faces_per_pixel=100, radius=4.0):
     from occlusionenv_amd.engine import OcclusionEngine
 
     n = n_env or case["mesh_ids"].shape[0]
     eng = OcclusionEngine(case["pool"], n, img, faces_per_pixel=faces_per_pixel)
     eng.set_scene(list(range(n)), case["mesh_ids"][:n], case["offsets"][:n])
-    obs0, loss0, fs0 = eng.reset_render(None, 4.0, case["az"][:n], 0.0)
+    obs0, loss0, fs0 = eng.reset_render(None, radius, case["az"][:n], 0.0)
     a = case["actions"][:n].to(eng.device).requires_grad_(True)
     obs, reward, done, fs, loss = eng.step(a)
     reward.sum().backward()
@@ -65,14 +65,14 @@ def run_engine(case, img, n_env=None, faces_per_pixel=100):
                 campos=eng.camera_position.cpu())
 
 
-def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_envs=None):
+def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_envs=None, radius=4.0):
     case = make_case(n_env, seed, mesh, az_range)
-    got = run_engine(case, img)
+    got = run_engine(case, img, radius=radius)
     res = dict(obs_maxabs=0.0, alpha_maxabs=0.0, fs_maxabs=0.0, loss_rel=0.0, reward_abs=0.0, grad_rel=0.0,
                obs0_maxabs=0.0, loss0_rel=0.0, depth_mismatch=0.0)
     for i in (check_envs if check_envs is not None else range(n_env)):
         env = oracle_env(case, i, img)
-        obs0 = env.reset(azimuth=float(case["az"][i]))
+        obs0 = env.reset(radius=radius, azimuth=float(case["az"][i]))
         a = case["actions"][i].clone().requires_grad_(True)
         obs, reward, done, info = env.step(a)
         reward.backward()

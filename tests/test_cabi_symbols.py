@@ -1,0 +1,66 @@
+"""The C-ABI shared library loads on a GPU-less host and exports every symbol include/*.h declares.
+No compute call is made here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "occlusionenv_amd.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(occ_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_declares_the_documented_entry_points():
+    names = _declared()
+    for n in ("occ_abi_version", "occ_camera", "occ_render", "occ_step_finish", "occ_workspace_query"):
+        assert n in names
+
+
+def test_library_exports_every_declared_symbol():
+    from occlusionenv_amd import _native
+
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    for n in _declared():
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+    assert set(_native.SYMBOLS) == set(_declared())
+    assert lib.occ_abi_version() == _native.ABI_VERSION
+
+
+def test_binding_constants_match_header():
+    from occlusionenv_amd import _native as nat
+
+    src = open(HEADER).read()
+
+    def define(name):
+        return int(re.search(rf"#define\s+{name}\s+(\d+)", src).group(1))
+
+    assert define("OCC_ABI_VERSION") == nat.ABI_VERSION and define("OCC_CAM_STRIDE") == nat.CAM_STRIDE
+    assert define("OCC_REC_STRIDE") == nat.REC_STRIDE and define("OCC_TILE") == nat.TILE
+    assert define("OCC_LIST_CAP") == nat.LIST_CAP and define("OCC_MAX_K") == nat.MAX_K
+    assert (define("OCC_RENDER_SOFT"), define("OCC_RENDER_HARD"), define("OCC_RENDER_GRAD")) == (1, 2, 4)
+    assert (define("OCC_CAM_STEP"), define("OCC_CAM_LOOKAT"), define("OCC_CAM_POSITION")) == (0, 1, 2)
+
+
+def test_workspace_query_and_argument_checks_need_no_gpu():
+    from occlusionenv_amd import _native as nat
+
+    lib = nat.load()
+    sc = nat.OccScene()
+    sc.n_env, sc.img, sc.rec_cap = 4, 128, 1000
+    sizes = nat.OccWorkspaceSizes()
+    assert lib.occ_workspace_query(ctypes.byref(sc), 64, ctypes.byref(sizes)) == 0
+    assert sizes.rec_bytes == 4 * 3 * 1000 * nat.REC_STRIDE * 4 and sizes.rec_bbox_bytes == 4 * 3 * 1000 * 4
+    assert sizes.partials_bytes == 4 * 16 * 16 * 16 and sizes.n_slots == 64
+    assert sizes.lists_bytes == 64 * nat.LIST_CAP * 64 * 20
+    sc.img = 100  # not a multiple of the tile size
+    assert lib.occ_workspace_query(ctypes.byref(sc), 64, ctypes.byref(sizes)) == 1
+    # null pointers are rejected before anything is launched
+    assert lib.occ_camera(0, None, None, None, None, None, None, 4, None) == 1
+    assert lib.occ_render(None, None, None, None, 3, 100, None) == 1
+    assert lib.occ_step_finish(None, None, None, None, None, None, None, None, 4, None) == 1

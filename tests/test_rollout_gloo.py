@@ -1,0 +1,64 @@
+"""N>1 path on CPU: env sharding + the single all-gather of rollout records, world_size 2 over gloo."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from occlusionenv_amd import rollout
+
+
+def test_env_shard_partitions_contiguously():
+    for n, w in [(8192, 8), (10, 3), (7, 7), (1024, 1)]:
+        spans = [rollout.env_shard(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_pack_records_layout():
+    obs = torch.rand(3, 4, 16, 16)
+    act, lp, rw = torch.rand(3, 2), torch.rand(3), torch.rand(3)
+    dn = torch.tensor([True, False, True])
+    rec = rollout.pack_records(obs, act, lp, rw, dn)
+    assert rec.shape == (3, rollout.RECORD_FLOATS) and rollout.RECORD_FLOATS * 4 == 1044
+    assert torch.allclose(rec[:, :256], torch.nn.functional.adaptive_avg_pool2d(obs, 8).reshape(3, 256))
+    assert torch.equal(rec[:, 256:258], act) and torch.equal(rec[:, 258], lp) and torch.equal(rec[:, 259], rw)
+    assert rec[:, 260].tolist() == [1.0, 0.0, 1.0]
+    assert rollout.all_gather_records(rec) is rec  # single process: no collective
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = rollout.env_shard(n_total, rank, world)
+    n = hi - lo
+    g = torch.Generator().manual_seed(100 + rank)
+    obs = torch.rand(n, 4, 16, 16, generator=g)
+    rec = rollout.pack_records(obs, torch.full((n, 2), float(rank)), torch.zeros(n),
+                               torch.arange(lo, hi, dtype=torch.float32), torch.zeros(n, dtype=torch.bool))
+    out = rollout.all_gather_records(rec)
+    q.put((rank, out[:, 259].tolist(), out[:, 256].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_records_world2_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n_total, world = 12, 2
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, rewards, a0 in res:
+        assert rewards == [float(i) for i in range(n_total)]  # rank-major == global env order
+        assert a0 == [0.0] * 6 + [1.0] * 6
