@@ -48,7 +48,7 @@ extern "C" {
 
 /* layout constants shared with the host */
 #define OCC_CAM_STRIDE 48  /* floats per env in the camera buffer */
-#define OCC_REC_STRIDE 40  /* floats per projected-face record */
+#define OCC_REC_STRIDE 36  /* floats per projected-face record (nine 16-byte parts) */
 #define OCC_TILE 8         /* pixels per tile side: one wave64 owns an 8x8 tile */
 #ifndef OCC_LIST_CAP
 #define OCC_LIST_CAP 512   /* per-pixel candidate list capacity; a full list is compacted in place to its K nearest */
@@ -82,19 +82,25 @@ typedef struct OccScene {
 /* Caller-allocated scratch; sizes from occ_workspace_query(). */
 typedef struct OccWorkspace {
     float* rec;         /* (n_env,3,rec_cap,OCC_REC_STRIDE) projected face records */
-    uint32_t* rec_bbox; /* (n_env,3,rec_cap) packed tile bbox */
+    uint32_t* rec_bbox; /* (n_env,3,rec_cap,2) conservative pixel bbox: xl|yl<<16, xh|yh<<16 */
     int32_t* nrec;      /* (n_env,3) */
     int32_t* objrect;   /* (n_env,3,4) tile rect tx0,ty0,tx1,ty1 (inclusive) */
     uint32_t* queue;    /* (16) work-queue head (zeroed by occ_render) */
     float* lists;       /* (n_slots,OCC_LIST_CAP,64,4) f32 payload rows, then (n_slots,OCC_LIST_CAP,64) u32 key rows */
-    float* partials;    /* (n_env,ntiles,4) per-tile loss / gradient partial sums */
+    float* partials;    /* (n_env,ceil(S*S/256),4) per-block loss / gradient partial sums */
     int32_t* status;    /* (n_env) OCC_STATUS_* bits, OR-ed in; caller clears */
+    int32_t* offsets;   /* (n_env*3+1) first work item of every (env, object) */
+    float* obj_alpha;   /* (n_env,3,S,S) per-object silhouette alpha, valid inside the object's tile rect */
+    float* obj_grad;    /* (n_env,3,S,S,2) d alpha / d(el, az) */
+    float* obj_hz;      /* (n_env,3,S,S) depth of the nearest face of the object (3e38 = none) */
+    int32_t* obj_hrec;  /* (n_env,3,S,S) its record index, -1 = none */
     int32_t n_slots;    /* persistent waves = blocks the tile kernel is launched with */
 } OccWorkspace;
 
 typedef struct OccWorkspaceSizes {
     size_t rec_bytes, rec_bbox_bytes, nrec_bytes, objrect_bytes, queue_bytes, lists_bytes,
-        partials_bytes, status_bytes;
+        partials_bytes, status_bytes, offsets_bytes, obj_alpha_bytes, obj_grad_bytes, obj_hz_bytes,
+        obj_hrec_bytes;
     int32_t n_slots; /* recommended persistent-wave count for this device */
 } OccWorkspaceSizes;
 
@@ -126,8 +132,9 @@ int occ_workspace_query(const OccScene* scene, int n_slots, OccWorkspaceSizes* o
 int occ_camera(int mode, const float* action, float* el, float* az, const float* radius,
                float* cam, float* cam_pos_out, int n_env, void* stream);
 
-/* Projection + z-clipping + culling + ordered face-record build, tile rasterisation (soft x3 +
- * hard), shading, loss and forward-mode gradient, for all envs. */
+/* Projection + z-clipping + culling + ordered face-record build, per-(env, object, tile) rasterisation
+ * (soft silhouette + nearest hard face), per-pixel combine (occlusion image, shading, loss and forward-mode
+ * gradient) and the per-env reduction, for all envs. */
 int occ_render(const OccScene* scene, const float* cam, const OccWorkspace* ws,
                const OccRenderOut* out, int flags, int faces_per_pixel, void* stream);
 
@@ -142,7 +149,7 @@ int occ_step_finish(const float* loss, const float* grad_elaz, const float* cam,
 
 /*
  * Measurement hooks (bench.py only; not part of the reference surface).  While enabled, occ_render
- * brackets its dominant kernel (occ_tile_kernel) with HIP events on the launch stream.
+ * brackets its dominant kernel (occ_raster_kernel) with HIP events on the launch stream.
  * occ_profile_read synchronises the recorded events (host sync!), returns the summed duration in
  * milliseconds and the number of launches since the last read -- counting only the launches with the
  * largest n_env seen (full batches; auto-resets render tiny ones) -- and resets the ring (max 4096 launches).

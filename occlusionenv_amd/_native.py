@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("OCC_HIP_LIB") or os.path.join(_HERE, "libocc_hip.so")
 # layout constants (must match include/occlusionenv_amd.h)
 ABI_VERSION = 1
 CAM_STRIDE = 48
-REC_STRIDE = 40
+REC_STRIDE = 36
 TILE = 8
 LIST_CAP = 512
 MAX_K = 128
@@ -52,6 +52,11 @@ class OccWorkspace(C.Structure):
         ("lists", C.c_void_p),
         ("partials", C.c_void_p),
         ("status", C.c_void_p),
+        ("offsets", C.c_void_p),
+        ("obj_alpha", C.c_void_p),
+        ("obj_grad", C.c_void_p),
+        ("obj_hz", C.c_void_p),
+        ("obj_hrec", C.c_void_p),
         ("n_slots", C.c_int32),
     ]
 
@@ -66,6 +71,11 @@ class OccWorkspaceSizes(C.Structure):
         ("lists_bytes", C.c_size_t),
         ("partials_bytes", C.c_size_t),
         ("status_bytes", C.c_size_t),
+        ("offsets_bytes", C.c_size_t),
+        ("obj_alpha_bytes", C.c_size_t),
+        ("obj_grad_bytes", C.c_size_t),
+        ("obj_hz_bytes", C.c_size_t),
+        ("obj_hrec_bytes", C.c_size_t),
         ("n_slots", C.c_int32),
     ]
 

@@ -1,7 +1,7 @@
 // occ_kernels.hip -- hand-written CDNA4 (gfx950) kernels for the batched OcclusionEnv step().
 //
 // What the reference does per environment through PyTorch3D (4 renders, ~200 autograd nodes,
-// /root/reference/environment.py:352-396) is done here for N environments in four launches:
+// /root/reference/environment.py:352-396) is done here for N environments in a fixed handful of launches:
 //
 //   occ_camera_kernel   one thread per env : action -> (el, az) -> C -> look_at R,T, carrying
 //                       forward-mode tangents d/d(el,az) of R and T (environment.py:356-368)
@@ -9,14 +9,16 @@
 //                       (MeshRasterizer.transform), z-clip (clip_faces), cull, per-face record
 //                       with NDC verts + tangents + invariants, ORDERED compaction (face order is
 //                       PyTorch3D's tie-break order), packed tile bbox, object tile rect
-//   occ_tile_kernel     persistent wave64 per 8x8-pixel tile (lane = pixel): on-the-fly binning by
-//                       ballot over packed bboxes, face records through the scalar cache (SGPRs),
-//                       three soft silhouettes (K nearest-z sigmoid product) + hard K=1 flat
-//                       shaded RGB-D in ONE sweep, candidate K-buffer (z, 1-p, grad) streamed to
-//                       HBM/L2 with 1-KiB coalesced rows, exact top-K-by-z selection when a pixel
-//                       has more than K candidates, occlusion image, loss and d loss/d(el,az) by
-//                       wave64 butterfly reductions
-//   occ_reduce_kernel   one wave per env: fixed-order sum of the per-tile partials
+//   occ_scan_kernel     prefix sum of the rect areas -> work items (env, object, tile inside the rect)
+//   occ_raster_kernel   persistent wave64 per work item; the 8x8 tile is cut into four 4x4 quadrants that
+//                       each stream their own face list (on-the-fly binning by ballot over pixel bboxes,
+//                       records staged in LDS by cooperative 16-B loads): soft silhouette (K nearest-z
+//                       sigmoid product) + hard nearest face of ONE object in one sweep, candidate K-buffer
+//                       (z, 1-p, grad) streamed to HBM/L2 in 1-KiB coalesced rows, exact top-K-by-z
+//                       selection (LDS-histogram radix select) when a pixel has more than K candidates
+//   occ_combine_kernel  one thread per pixel: occlusion image of the three silhouettes, loss and
+//                       d loss/d(el,az) partials, nearest-object pick + flat shading, outputs
+//   occ_reduce_kernel   one wave per env: fixed-order sum of the per-block partials
 //   occ_finish_kernel   reward bookkeeping + action Jacobian (environment.py:381-392,356-361)
 //
 // The gradient is carried in FORWARD mode (two tangent directions, el and az) through the very
@@ -255,7 +257,7 @@ __device__ __forceinline__ PVert cut_edge(const VVert& a, const VVert& b) {
 
 struct Tri {
     PVert v[3];
-    uint32_t bbox;  // packed tile bbox
+    uint2 bbox;  // conservative pixel bbox: x = xl | yl << 16, y = xh | yh << 16
     int tx0, ty0, tx1, ty1;
 };
 
@@ -273,8 +275,10 @@ __device__ __forceinline__ bool finish_tri(Tri& t, int S) {
     // pixel index of an NDC coordinate: u(f) = (S-1) - ((f+1)*S - 1)/2   (decreasing)
     const float fS = (float)S;
     auto u = [&](float f) { return (fS - 1.0f) - ((f + 1.0f) * fS - 1.0f) * 0.5f; };
-    int xl = (int)floorf(u(bx1) - 0.01f), xh = (int)ceilf(u(bx0) + 0.01f);
-    int yl = (int)floorf(u(by1) - 0.01f), yh = (int)ceilf(u(by0) + 0.01f);
+    // pixels whose centre can pass the exact float test bx0 <= xf <= bx1 (u is decreasing); 1e-3 px of slack
+    // covers the rounding of u() - the per-pixel float test in eval_face stays the authority
+    int xl = (int)ceilf(u(bx1) - 1e-3f), xh = (int)floorf(u(bx0) + 1e-3f);
+    int yl = (int)ceilf(u(by1) - 1e-3f), yh = (int)floorf(u(by0) + 1e-3f);
     xl = max(xl, 0);
     yl = max(yl, 0);
     xh = min(xh, S - 1);
@@ -284,12 +288,12 @@ __device__ __forceinline__ bool finish_tri(Tri& t, int S) {
     t.tx1 = xh / OCC_TILE;
     t.ty0 = yl / OCC_TILE;
     t.ty1 = yh / OCC_TILE;
-    t.bbox = (uint32_t)t.tx0 | ((uint32_t)t.ty0 << 8) | ((uint32_t)t.tx1 << 16) | ((uint32_t)t.ty1 << 24);
+    t.bbox = make_uint2((uint32_t)xl | ((uint32_t)yl << 16), (uint32_t)xh | ((uint32_t)yh << 16));
     return true;
 }
 
 template <bool GRAD>
-__device__ __forceinline__ void write_record(float* __restrict__ r, uint32_t* __restrict__ bb, const Tri& t,
+__device__ __forceinline__ void write_record(float* __restrict__ r, uint2* __restrict__ bb, const Tri& t,
                                              int face_id, int flags) {
     const float x0 = t.v[0].x, y0 = t.v[0].y, x1 = t.v[1].x, y1 = t.v[1].y, x2 = t.v[2].x, y2 = t.v[2].y;
     float o[OCC_REC_STRIDE];
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(256) void occ_setup_kernel(OccScene sc, const float
     }
     __syncthreads();
     float* __restrict__ rec = ws.rec + (size_t)eo * sc.rec_cap * OCC_REC_STRIDE;
-    uint32_t* __restrict__ bbs = ws.rec_bbox + (size_t)eo * sc.rec_cap;
+    uint2* __restrict__ bbs = reinterpret_cast<uint2*>(ws.rec_bbox) + (size_t)eo * sc.rec_cap;
     int total = 0;
     bool overflow = false;
     for (int base = 0; base < nF; base += 256) {
@@ -706,7 +710,14 @@ __device__ __forceinline__ void topk_select(float4* __restrict__ list, uint32_t*
     Tmax = tmax;
 }
 
-struct TileParams {
+#ifdef OCC_DBG_STATS  // diagnostic build only: loop trip counts of the raster kernel
+__device__ unsigned long long g_dbg_stats[8];
+#define OCC_STAT(i, v) do { if (lane == 0) atomicAdd(&g_dbg_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define OCC_STAT(i, v) do { } while (0)
+#endif
+
+struct RasterParams {
     OccScene sc;
     OccWorkspace ws;
     OccRenderOut out;
@@ -715,307 +726,436 @@ struct TileParams {
     int ntx;  // tiles per image side
 };
 
-constexpr int kChunkMax = 4;  // tiles dequeued per atomic (fewer when the batch is small)
+// One block: exclusive prefix sum of the tile counts of every (env, object) rect -> work-item offsets.
+__global__ __launch_bounds__(1024) void occ_scan_kernel(const int* __restrict__ objrect, const int* __restrict__ nrec,
+                                                        int* __restrict__ offsets, int M) {
+    __shared__ int s_part[16];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < M; base += 1024) {
+        const int i = base + tid;
+        int c = 0;
+        if (i < M && nrec[i] > 0) {
+            const int w = objrect[4 * i + 2] - objrect[4 * i] + 1, h = objrect[4 * i + 3] - objrect[4 * i + 1] + 1;
+            c = (w > 0 && h > 0) ? w * h : 0;
+        }
+        int incl = c;  // inclusive scan inside the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) s_part[wave] = incl;
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int v = s_part[w];
+            if (w < wave) woff += v;
+            tot += v;
+        }
+        const int carry = s_carry;
+        if (i < M) offsets[i] = carry + woff + incl - c;
+        __syncthreads();
+        if (tid == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    if (tid == 0) offsets[M] = s_carry;
+}
 
+// ------------------------------------------------------------------------------------------
+// raster kernel: one persistent wave64 per work item (env, object, 8x8 tile inside the object's rect)
+// ------------------------------------------------------------------------------------------
+// Lane layout: the tile is cut into four 4x4 QUADRANTS; quadrant q owns lanes 16q..16q+15.  Every quadrant
+// streams its OWN list of faces (those whose pixel bbox touches it), so one loop iteration evaluates four
+// different faces - a face whose footprint (~5x5 px with the blur margin) covers a quarter of the tile no
+// longer costs a 64-lane pass.  A pixel belongs to exactly one quadrant and each quadrant visits its faces
+// in index order, so the per-pixel candidate order (PyTorch3D's tie-break) is unchanged.
 template <bool SOFT, bool HARD, bool GRAD>
-__global__ __launch_bounds__(64) void occ_tile_kernel(TileParams P) {
+__global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
     const int lane = threadIdx.x;
+    const int q = lane >> 4, l = lane & 15;
+    const int px = (q & 1) * 4 + (l & 3), py = (q >> 1) * 4 + (l >> 2);
     const int S = P.sc.img;
-    const int ntx = P.ntx, ntiles = ntx * ntx;
-    const int total_items = P.sc.n_env * ntiles;
+    const int M = P.sc.n_env * 3;
+    const float fS = (float)S;
+    const int cap = P.sc.rec_cap;
+    const int K = P.K;
     // per-wave K-buffer: payload rows (float4) for every slot first, then the compact key rows
     float4* __restrict__ mylist = reinterpret_cast<float4*>(P.ws.lists) + (size_t)blockIdx.x * OCC_LIST_CAP * 64;
     uint32_t* __restrict__ mykeys = reinterpret_cast<uint32_t*>(reinterpret_cast<float4*>(P.ws.lists) +
                                                                 (size_t)gridDim.x * OCC_LIST_CAP * 64) +
                                     (size_t)blockIdx.x * OCC_LIST_CAP * 64;
     __shared__ uint32_t s_hist[64 * 17];
-    // face records of the current 64-face chunk that overlap this tile, staged by cooperative 16-B loads
-    // (one memory latency per chunk instead of one per face); slot 64 holds a clipped pair's partner that
-    // falls into the next chunk
+    // face records of the current 64-face chunk that touch this tile, staged by cooperative 16-B loads
     constexpr int kParts = GRAD ? 9 : (SOFT ? 6 : 4);  // float4 parts of a record that this variant reads
-    __shared__ float4 s_stage[65 * 10];
+    __shared__ float4 s_stage[64 * 9];
     __shared__ int s_hit[64];
-    const float fS = (float)S;
-    const int cap = P.sc.rec_cap;
-    const int K = P.K;
+    // s_qlist[q][i] = (staged slot << 8 | chunk bit) of the i-th face of quadrant q in the current chunk
+    __shared__ unsigned short s_qlist[4][64];
+    ciptr offs = as_const(P.ws.offsets);
+    const int total_items = offs[M];
 
-    // Two sweeps over the same (env, tile) item space, each with its own queue head: sweep 0 takes the tiles
-    // some object's rect covers (one tile per dequeue: they cost 0.1-1 ms each), sweep 1 the background tiles
-    // (16 per dequeue: they only write defaults).  The cheap items land at the end of the launch, so its tail
-    // is at most one heavy tile long instead of one chunk of heavy tiles.
-    for (int sweep = 0; sweep < 2; ++sweep) {
-    const int kChunk = sweep == 0 ? 1 : kChunkMax * 4;
     for (;;) {
-        int start = 0;
-        if (lane == 0) start = (int)atomicAdd(P.ws.queue + sweep, (uint32_t)kChunk);
-        start = __builtin_amdgcn_readfirstlane(start);
-        if (start >= total_items) break;
-        const int stop = min(start + kChunk, total_items);
-        for (int item = start; item < stop; ++item) {
-            const int env = item / ntiles;
-            const int t = item - env * ntiles;
-            const int ty = t / ntx, tx = t - ty * ntx;
-            {
-                ciptr rc = as_const(P.ws.objrect + env * 12);
-                bool occupied = false;
-#pragma unroll
-                for (int o = 0; o < 3; ++o)
-                    occupied |= !(tx < rc[4 * o] || ty < rc[4 * o + 1] || tx > rc[4 * o + 2] || ty > rc[4 * o + 3]);
-                if (occupied != (sweep == 0)) continue;
+        int item = 0;
+        if (lane == 0) item = (int)atomicAdd(P.ws.queue, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= total_items) break;
+        // (env, object) of this item: largest eo with offsets[eo] <= item
+        int lo = 0, hi = M;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (offs[mid] <= item) lo = mid; else hi = mid;
+        }
+        const int eo = lo;
+        const int local = item - offs[eo];
+        ciptr rect = as_const(P.ws.objrect + eo * 4);
+        const int rw = rect[2] - rect[0] + 1;
+        const int ty = rect[1] + local / rw, tx = rect[0] + local % rw;
+        const int xi = tx * OCC_TILE + px, yi = ty * OCC_TILE + py;
+        // [P3D] pixel centre in NDC, +X left, +Y up
+        const float xf = -1.0f + (2.0f * (float)(S - 1 - xi) + 1.0f) / fS;
+        const float yf = -1.0f + (2.0f * (float)(S - 1 - yi) + 1.0f) / fS;
+        const int n = as_const(P.ws.nrec + eo)[0];
+        OCC_STAT(0, 1);              // work items
+#ifdef OCC_DBG_STATS
+        int dbg_p0 = 0, dbg_p1 = 0, dbg_p2 = 0, dbg_p3 = 0;
+#endif
+        OCC_STAT(5, (n + 63) / 64);  // chunks scanned
+        const float* __restrict__ recs = P.ws.rec + (size_t)eo * cap * OCC_REC_STRIDE;
+        const uint2* __restrict__ bbs = reinterpret_cast<const uint2*>(P.ws.rec_bbox) + (size_t)eo * cap;
+
+        float hz = 3.0e38f;
+        int hrec = -1;
+        int count = 0;
+        float prod = 1.0f, sge = 0.f, sga = 0.f;
+        bool thr_on = false;   // set once this lane's list has been compacted to its K nearest
+        uint32_t thrT = 0;     // key of the K-th nearest so far: later candidates need key < thrT
+        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;  // key range of the stored candidates
+        Cand pend;             // first half of a clipped pair waiting for its partner
+        bool pend_on = false;
+        int pend_j = -2;       // record index of the waiting half
+        pend.cand = false; pend.inside = false; pend.z = pend.zh = pend.ad = 0.f; pend.q = 1.f; pend.ge = pend.ga = 0.f; pend.amin = 0;
+
+        auto commit = [&](bool cnd, float z, float qv, float ge, float ga) {
+            const uint32_t key = zkey(z);
+            bool acc = cnd && (!thr_on || key < thrT);
+            if (__ballot(acc && count >= OCC_LIST_CAP)) {
+                // rare: a pixel collected OCC_LIST_CAP candidates -> keep its K nearest, go on
+                const bool full = count >= OCC_LIST_CAP;
+                float pr, se, sa;
+                uint32_t T;
+                topk_select<true>(mylist, mykeys, s_hist, lane, count, K, full, kmin, kmax, pr, se, sa, T);
+                if (full) {
+                    count = K;
+                    thr_on = true;
+                    thrT = T;
+                    kmax = T;
+                    acc = cnd && (key < thrT);
+                }
             }
-            const int xi = tx * OCC_TILE + (lane & 7), yi = ty * OCC_TILE + (lane >> 3);
-            // [P3D] pixel centre in NDC, +X left, +Y up
-            const float xf = -1.0f + (2.0f * (float)(S - 1 - xi) + 1.0f) / fS;
-            const float yf = -1.0f + (2.0f * (float)(S - 1 - yi) + 1.0f) / fS;
-            float alpha[3] = {0.f, 0.f, 0.f};
-            float dae[3] = {0.f, 0.f, 0.f}, daa[3] = {0.f, 0.f, 0.f};
-            float hz = 3.0e38f;
-            int hrec = -1;  // (object * cap + record) of the nearest hard face
-
-#pragma unroll 1
-            for (int o = 0; o < 3; ++o) {
-                const int eo = env * 3 + o;
-                ciptr rect = as_const(P.ws.objrect + eo * 4);
-                if (tx < rect[0] || ty < rect[1] || tx > rect[2] || ty > rect[3]) continue;
-                const int n = as_const(P.ws.nrec + eo)[0];
-                const float* __restrict__ recs = P.ws.rec + (size_t)eo * cap * OCC_REC_STRIDE;
-                const uint32_t* __restrict__ bbs = P.ws.rec_bbox + (size_t)eo * cap;
-                int count = 0;
-                float prod = 1.0f, sge = 0.f, sga = 0.f;
-                bool skip0 = false;
-
-                bool thr_on = false;   // set once this lane's list has been compacted to its K nearest
-                uint32_t thrT = 0;     // key of the K-th nearest so far: later candidates need key < thrT
-                uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;  // key range of the stored candidates
-                auto commit = [&](bool cnd, float z, float q, float ge, float ga) {
-                    const uint32_t key = zkey(z);
-                    bool acc = cnd && (!thr_on || key < thrT);
-                    if (__ballot(acc && count >= OCC_LIST_CAP)) {
-                        // rare: a pixel collected OCC_LIST_CAP candidates -> keep its K nearest, go on
-                        const bool full = count >= OCC_LIST_CAP;
-                        float pr, se, sa;
-                        uint32_t T;
-                        topk_select<true>(mylist, mykeys, s_hist, lane, count, K, full, kmin, kmax, pr, se, sa, T);
-                        if (full) {
-                            count = K;
-                            thr_on = true;
-                            thrT = T;
-                            kmax = T;
-                            acc = cnd && (key < thrT);
-                        }
-                    }
-                    if (acc) {
+            if (acc) {
 #ifndef OCC_DBG_NO_STORE  // timing experiment only
-                        mylist[(size_t)count * 64 + lane] = make_float4(z, q, ge, ga);
-                        mykeys[(size_t)count * 64 + lane] = key;
+                mylist[(size_t)count * 64 + lane] = make_float4(z, qv, ge, ga);
+                mykeys[(size_t)count * 64 + lane] = key;
 #endif
-                        kmin = min(kmin, key);
-                        kmax = max(kmax, key);
-                        count += 1;
-                        prod *= q;
-                        sge += ge;
-                        sga += ga;
-                    }
-                };
-                auto hard_update = [&](const Cand& c, int j) {
-                    if (HARD) {
-                        if (c.inside && c.zh < hz) {
-                            hz = c.zh;
-                            hrec = o * cap + j;
-                        }
-                    }
-                };
+                kmin = min(kmin, key);
+                kmax = max(kmax, key);
+                count += 1;
+                prod *= qv;
+                sge += ge;
+                sga += ga;
+            }
+        };
 
-                for (int c0 = 0; c0 < n; c0 += 64) {
-                    const int jj = c0 + lane;
-                    uint32_t bb = 0x000000FFu;  // tx0 = 255 > tx1 = 0: never overlaps
-                    if (jj < n) bb = bbs[jj];
-                    const int bx0 = bb & 0xFF, by0 = (bb >> 8) & 0xFF, bx1 = (bb >> 16) & 0xFF, by1 = bb >> 24;
-                    const bool hit = (bx0 <= tx) && (tx <= bx1) && (by0 <= ty) && (ty <= by1);
-                    unsigned long long mask = __ballot(hit);
-                    if (skip0) {
-                        mask &= ~1ull;
-                        skip0 = false;
-                    }
-                    if (mask) {
-                        const int nh = __popcll(mask);
-                        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-                        if (hit && ((mask >> lane) & 1ull)) s_hit[__popcll(mask & lt)] = lane;
-                        __syncthreads();
-                        for (int idx = lane; idx < nh * kParts; idx += 64) {
-                            const int k = idx / kParts, part = idx - k * kParts;
-                            const int j = c0 + s_hit[k];
-                            s_stage[k * 10 + part] = reinterpret_cast<const float4*>(recs + (size_t)j * OCC_REC_STRIDE)[part];
-                        }
-                        __syncthreads();
-                        for (int k = 0; k < nh; ++k) {
-                            const int bit = __builtin_amdgcn_readfirstlane(s_hit[k]);
-                            const int j = c0 + bit;
-                            const float4* rs = &s_stage[k * 10];
-                            const int flags = __builtin_amdgcn_readfirstlane(__float_as_int(rs[2].z));
-                            Cand c1;
-                            eval_face<SOFT, GRAD>(OCC_REC_LOAD(rs, kParts), xf, yf, c1);
-                            hard_update(c1, j);
-                            if (flags & FLAG_PAIR_FIRST) {
-                                // clipped quad split in two: only the nearer-in-|d| of the pair may
-                                // enter a pixel's list
-                                bool second_hit = false;
-                                const float4* r2 = &s_stage[(k + 1) * 10];
-                                if (bit < 63) {
-                                    second_hit = (k + 1 < nh) && (__builtin_amdgcn_readfirstlane(s_hit[k + 1]) == bit + 1);
-                                } else if (j + 1 < n) {
-                                    const uint32_t b2 = bbs[j + 1];
-                                    second_hit = ((int)(b2 & 0xFF) <= tx) && (tx <= (int)((b2 >> 16) & 0xFF)) &&
-                                                 ((int)((b2 >> 8) & 0xFF) <= ty) && (ty <= (int)(b2 >> 24));
-                                    if (second_hit) {
-                                        skip0 = true;
-                                        if (lane < kParts)
-                                            s_stage[64 * 10 + lane] =
-                                                reinterpret_cast<const float4*>(recs + (size_t)(j + 1) * OCC_REC_STRIDE)[lane];
-                                        __syncthreads();
-                                        r2 = &s_stage[64 * 10];
-                                    }
-                                }
-                                if (second_hit) {
-                                    Cand c2;
-                                    eval_face<SOFT, GRAD>(OCC_REC_LOAD(r2, kParts), xf, yf, c2);
-                                    hard_update(c2, j + 1);
-                                    // [P3D]: the second half replaces the first iff its |d| is strictly smaller.
-                                    // If both are closest to the diagonal they share (t1: edge (v1,v2), t2: edge
-                                    // (v0,v1)) the two distances are equal in exact arithmetic: keep the first.
-                                    const bool shared_tie = (c1.amin == 2) && (c2.amin == 0);
-                                    const bool take2 = c2.cand && (!c1.cand || (!shared_tie && c2.ad < c1.ad));
-                                    if (take2) c1 = c2;
-                                    if (bit < 63) k += 1;  // the partner was the next staged record: consumed
-                                }
-                            }
-                            if (SOFT) commit(c1.cand, c1.z, c1.q, c1.ge, c1.ga);
-                        }
-                        __syncthreads();
+        // pixel rectangles of the four quadrants (wave-uniform)
+        const int tx8 = tx * OCC_TILE, ty8 = ty * OCC_TILE;
+        uint2 bb_next = make_uint2(0xFFFFu, 0u);
+        if (lane < n) bb_next = bbs[lane];
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const uint2 bb = bb_next;
+            bb_next = make_uint2(0xFFFFu, 0u);  // x0 = 65535 > any pixel: never overlaps
+            if (c0 + 64 + lane < n) bb_next = bbs[c0 + 64 + lane];
+            const int rx0 = bb.x & 0xFFFF, ry0 = bb.x >> 16, rx1 = bb.y & 0xFFFF, ry1 = bb.y >> 16;
+            const bool hx0 = (rx0 <= tx8 + 3) && (rx1 >= tx8), hx1 = (rx0 <= tx8 + 7) && (rx1 >= tx8 + 4);
+            const bool hy0 = (ry0 <= ty8 + 3) && (ry1 >= ty8), hy1 = (ry0 <= ty8 + 7) && (ry1 >= ty8 + 4);
+            unsigned long long m0 = __ballot(hx0 && hy0), m1 = __ballot(hx1 && hy0);
+            unsigned long long m2 = __ballot(hx0 && hy1), m3 = __ballot(hx1 && hy1);
+            const unsigned long long mu = m0 | m1 | m2 | m3;
+            if (!mu) continue;
+            const int nh = __popcll(mu);
+            const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            if ((mu >> lane) & 1ull) {
+                const int myslot = __popcll(mu & lt);
+                s_hit[myslot] = lane;
+                const unsigned short ent = (unsigned short)((myslot << 8) | lane);
+                if ((m0 >> lane) & 1ull) s_qlist[0][__popcll(m0 & lt)] = ent;
+                if ((m1 >> lane) & 1ull) s_qlist[1][__popcll(m1 & lt)] = ent;
+                if ((m2 >> lane) & 1ull) s_qlist[2][__popcll(m2 & lt)] = ent;
+                if ((m3 >> lane) & 1ull) s_qlist[3][__popcll(m3 & lt)] = ent;
+            }
+            __syncthreads();
+#ifndef OCC_DBG_NO_STAGE  // timing experiment only
+            for (int idx = lane; idx < nh * kParts; idx += 64) {
+                const int k = idx / kParts, part = idx - k * kParts;
+                const int j = c0 + s_hit[k];
+                s_stage[k * 9 + part] = reinterpret_cast<const float4*>(recs + (size_t)j * OCC_REC_STRIDE)[part];
+            }
+#endif
+            __syncthreads();
+            const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+            const int nq = (q == 0) ? n0 : ((q == 1) ? n1 : ((q == 2) ? n2 : n3));
+            int niter = max(max(n0, n1), max(n2, n3));
+            OCC_STAT(1, 1);                  // chunks with at least one hit
+            OCC_STAT(2, nh);                 // staged records
+            OCC_STAT(3, niter);              // eval iterations
+            OCC_STAT(4, n0 + n1 + n2 + n3);  // (face, quadrant) pairs
+#ifdef OCC_DBG_STATS
+            dbg_p0 += n0; dbg_p1 += n1; dbg_p2 += n2; dbg_p3 += n3;
+#endif
+#ifdef OCC_DBG_NO_EVAL  // timing experiment only
+            niter = 0;
+#endif
+            for (int it = 0; it < niter; ++it) {
+                // the it-th face of this lane's quadrant -> its staged slot and chunk bit
+                const bool active = it < nq;
+                const int ent = active ? (int)s_qlist[q][it] : 0;
+                const int slot = ent >> 8, jb = ent & 0xFF;
+                const int j = c0 + jb;
+                const float4* rs = &s_stage[(active ? slot : 0) * 9];
+                Cand c1;
+                eval_face<SOFT, GRAD>(OCC_REC_LOAD(rs, kParts), xf, yf, c1);
+                c1.cand = c1.cand && active;
+                c1.inside = c1.inside && active;
+                if (HARD) {
+                    if (c1.inside && c1.zh < hz) {
+                        hz = c1.zh;
+                        hrec = j;
                     }
                 }
-
                 if (SOFT) {
-                    // more than K candidates: keep the K nearest in z (ties: earlier face first), SURVEY A.4
-#ifdef OCC_DBG_NO_TOPK  // timing experiment only: skip the exact selection (results wrong where count > K)
-                    const bool ovf = false;
-#else
-                    const bool ovf = (count > K) || thr_on;
-#endif
-                    if (__ballot(ovf)) {
-                        float pr, se, sa;
-                        uint32_t T;
-                        topk_select<false>(mylist, mykeys, s_hist, lane, count, K, ovf, kmin, kmax, pr, se, sa, T);
-                        if (ovf) {
-                            prod = pr;
-                            sge = se;
-                            sga = sa;
+                    const int flags = active ? __float_as_int(rs[2].z) : 0;
+                    const bool is_second = ((flags & FLAG_PAIR_SECOND) != 0) && pend_on && (j == pend_j + 1);
+                    // a waiting first half whose partner is not the face at hand goes in on its own
+                    const bool flush = pend_on && !is_second && active;
+                    if (__ballot(flush)) {
+                        commit(flush && pend.cand, pend.z, pend.q, pend.ge, pend.ga);
+                        if (flush) pend_on = false;
+                    }
+                    if (__ballot(pend_on && is_second)) {
+                        // [P3D]: the second half replaces the first iff its |d| is strictly smaller.  If both are
+                        // closest to the diagonal they share (t1: edge (v1,v2), t2: edge (v0,v1)) the distances
+                        // are equal in exact arithmetic: keep the first.
+                        if (pend_on && is_second) {
+                            const bool shared_tie = (pend.amin == 2) && (c1.amin == 0);
+                            const bool take2 = c1.cand && (!pend.cand || (!shared_tie && c1.ad < pend.ad));
+                            if (!take2) c1 = pend;
+                            pend_on = false;
                         }
                     }
-                    alpha[o] = 1.0f - prod;
-                    if (GRAD) {
-                        // d alpha/d theta = -(A/sigma) * sum_k p_k d(d_k)/d theta   
-                        const float coef = -prod * kInvSigma;
-                        dae[o] = coef * sge;
-                        daa[o] = coef * sga;
+                    const bool is_first = (flags & FLAG_PAIR_FIRST) != 0;
+                    if (__ballot(is_first)) {
+                        if (is_first) {
+                            pend = c1;
+                            pend_on = true;
+                            pend_j = j;
+                            c1.cand = false;
+                        }
                     }
+                    commit(c1.cand, c1.z, c1.q, c1.ge, c1.ga);
                 }
             }
+            __syncthreads();
+        }
+#ifdef OCC_DBG_STATS
+        OCC_STAT(6, max(max(dbg_p0, dbg_p1), max(dbg_p2, dbg_p3)));  // iterations if quadrants streamed freely
+#endif
+        const size_t opix = ((size_t)eo * S + yi) * S + xi;
+        if (SOFT) {
+            if (__ballot(pend_on)) {
+                commit(pend_on && pend.cand, pend.z, pend.q, pend.ge, pend.ga);
+                pend_on = false;
+            }
+            // more than K candidates: keep the K nearest in z (ties: earlier face first), SURVEY A.4
+#ifdef OCC_DBG_NO_TOPK  // timing experiment only: skip the exact selection (results wrong where count > K)
+            const bool ovf = false;
+#else
+            const bool ovf = (count > K) || thr_on;
+#endif
+            if (__ballot(ovf)) {
+                float pr, se, sa;
+                uint32_t T;
+                topk_select<false>(mylist, mykeys, s_hist, lane, count, K, ovf, kmin, kmax, pr, se, sa, T);
+                if (ovf) {
+                    prod = pr;
+                    sge = se;
+                    sga = sa;
+                }
+            }
+            P.ws.obj_alpha[opix] = 1.0f - prod;
+            if (GRAD) {
+                // d alpha/d theta = -(A/sigma) * sum_k p_k d(d_k)/d theta   
+                const float coef = -prod * kInvSigma;
+                reinterpret_cast<float2*>(P.ws.obj_grad)[opix] = make_float2(coef * sge, coef * sga);
+            }
+        }
+        if (HARD) {
+            P.ws.obj_hz[opix] = hz;
+            P.ws.obj_hrec[opix] = hrec;
+        }
+    }
+}
 
-            // ---- per-pixel epilogue -------------------------------------------------------
-            const size_t pix = (size_t)yi * S + xi;
+// ------------------------------------------------------------------------------------------
+// combine kernel: one thread per pixel - occlusion image, loss / gradient partials, shading, outputs
+// ------------------------------------------------------------------------------------------
+template <bool SOFT, bool HARD, bool GRAD>
+__global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bpe) {
+    __shared__ float s_red[4][3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int env = blockIdx.x / bpe, blk = blockIdx.x - env * bpe;
+    const int S = P.sc.img;
+    const int pix = blk * 256 + tid;
+    const bool live = pix < S * S;
+    const int yi = live ? pix / S : 0, xi = live ? pix - (pix / S) * S : 0;
+    const int tx = xi / OCC_TILE, ty = yi / OCC_TILE;
+    const int cap = P.sc.rec_cap;
+    float alpha[3] = {0.f, 0.f, 0.f}, dae[3] = {0.f, 0.f, 0.f}, daa[3] = {0.f, 0.f, 0.f};
+    float hz = 3.0e38f;
+    int hrec = -1, hobj = 0;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const int eo = env * 3 + o;
+        ciptr rect = as_const(P.ws.objrect + eo * 4);
+        const bool in = live && as_const(P.ws.nrec + eo)[0] > 0 && tx >= rect[0] && ty >= rect[1] && tx <= rect[2] &&
+                        ty <= rect[3];
+        if (in) {
+            const size_t opix = ((size_t)eo * S + yi) * S + xi;
             if (SOFT) {
-                // environment.py:373: image = i1*i2 + i2*i3 + i1*i3 ; RGB of every silhouette is 1
-                const float I = alpha[0] * alpha[1] + alpha[1] * alpha[2] + alpha[0] * alpha[2];
-                float l = I * I, ge = 0.f, ga = 0.f;
+                alpha[o] = P.ws.obj_alpha[opix];
                 if (GRAD) {
-                    const float g0 = alpha[1] + alpha[2], g1 = alpha[0] + alpha[2], g2 = alpha[0] + alpha[1];
-                    ge = 2.0f * I * (g0 * dae[0] + g1 * dae[1] + g2 * dae[2]);
-                    ga = 2.0f * I * (g0 * daa[0] + g1 * daa[1] + g2 * daa[2]);
-                }
-                l = wave_sum(l);
-                if (GRAD) {
-                    ge = wave_sum(ge);
-                    ga = wave_sum(ga);
-                }
-                if (lane == 0) {
-                    reinterpret_cast<float4*>(P.ws.partials)[item] = make_float4(l, ge, ga, 0.f);
-                }
-                if (P.out.full_state) {
-                    reinterpret_cast<float4*>(P.out.full_state)[(size_t)env * S * S + pix] = make_float4(3.f, 3.f, 3.f, I);
-                }
-                if (P.out.alphas) {
-                    float* __restrict__ al = P.out.alphas + (size_t)env * 3 * S * S + pix;
-                    al[0] = alpha[0];
-                    al[(size_t)S * S] = alpha[1];
-                    al[(size_t)2 * S * S] = alpha[2];
+                    const float2 g = reinterpret_cast<const float2*>(P.ws.obj_grad)[opix];
+                    dae[o] = g.x;
+                    daa[o] = g.y;
                 }
             }
             if (HARD) {
-                // [P3D] HardFlatShader + hard_rgb_blend; depth in channel 3 (environment.py:378)
-                float cr = 1.f, cg = 1.f, cb = 1.f, depth = -1.f;
-                if (hrec >= 0) {
-                    const int o = hrec / cap, j = hrec - o * cap;
-                    const int eo = env * 3 + o;
-                    const float* __restrict__ r = P.ws.rec + ((size_t)eo * cap + j) * OCC_REC_STRIDE;
-                    const int fid = __float_as_int(r[R_ID]);
-                    const int mesh = P.sc.scene_mesh[eo];
-                    const int vo = P.sc.mesh_vert_off[mesh], fo = P.sc.mesh_face_off[mesh];
-                    const float ox = P.sc.scene_offset[eo * 3], oy = P.sc.scene_offset[eo * 3 + 1],
-                                oz = P.sc.scene_offset[eo * 3 + 2];
-                    float w[3][3];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const int vi = P.sc.pool_faces[(size_t)(fo + fid) * 3 + k];
-                        const float* pv = P.sc.pool_verts + (size_t)(vo + vi) * 3;
-                        w[k][0] = pv[0] + ox;
-                        w[k][1] = pv[1] + oy;
-                        w[k][2] = pv[2] + oz;
-                    }
-                    const float ax = w[1][0] - w[0][0], ay = w[1][1] - w[0][1], az = w[1][2] - w[0][2];
-                    const float bx = w[2][0] - w[0][0], by = w[2][1] - w[0][1], bz = w[2][2] - w[0][2];
-                    float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
-                    float nn = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), kShadeEps);
-                    nx /= nn; ny /= nn; nz /= nn;
-                    nn = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), kShadeEps);  // F.normalize again in diffuse()/specular()
-                    nx /= nn; ny /= nn; nz /= nn;
-                    const float ccx = (w[0][0] + w[1][0] + w[2][0]) / 3.0f, ccy = (w[0][1] + w[1][1] + w[2][1]) / 3.0f,
-                                ccz = (w[0][2] + w[1][2] + w[2][2]) / 3.0f;
-                    float lx = kLightX - ccx, ly = kLightY - ccy, lz = kLightZ - ccz;
-                    const float ln = fmaxf(sqrtf(lx * lx + ly * ly + lz * lz), kShadeEps);
-                    lx /= ln; ly /= ln; lz /= ln;
-                    const float cosang = nx * lx + ny * ly + nz * lz;
-                    const float diffuse = kDiffuse * fmaxf(cosang, 0.f);
-                    const float* __restrict__ cm = P.cam + (size_t)env * OCC_CAM_STRIDE;
-                    float vx = cm[C_C] - ccx, vy = cm[C_C + 1] - ccy, vz = cm[C_C + 2] - ccz;
-                    const float vn = fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), kShadeEps);
-                    vx /= vn; vy /= vn; vz /= vn;
-                    const float rx = -lx + 2.f * (cosang * nx), ry = -ly + 2.f * (cosang * ny), rz = -lz + 2.f * (cosang * nz);
-                    float sa = fmaxf(vx * rx + vy * ry + vz * rz, 0.f) * (cosang > 0.f ? 1.f : 0.f);
-                    sa *= sa; sa *= sa; sa *= sa; sa *= sa; sa *= sa; sa *= sa;  // ^64
-                    const float spec = kSpecular * sa;
-                    // texel: white TexturesVertex interpolated with the (unclipped) barycentrics
-                    const float x0 = r[R_X0], y0 = r[R_Y0], z0 = r[R_Z0], x1 = r[R_X1], y1 = r[R_Y1], z1 = r[R_Z1];
-                    const float x2 = r[R_X2], y2 = r[R_Y2], z2 = r[R_Z2];
-                    const float ia = r[R_INV_AREA];
-                    const float b0 = ((xf - x1) * (y2 - y1) - (yf - y1) * (x2 - x1)) * ia;
-                    const float b1 = ((yf - y2) * (x2 - x0) - (xf - x2) * (y2 - y0)) * ia;
-                    const float b2 = ((xf - x0) * (y1 - y0) - (yf - y0) * (x1 - x0)) * ia;
-                    const float w0 = b0 * z1 * z2, w1 = z0 * b1 * z2, w2 = z0 * z1 * b2;
-                    const float den = fmaxf(w0 + w1 + w2, kEpsilon);
-                    const float texel = w0 / den + w1 / den + w2 / den;
-                    const float col = (kAmbient + diffuse) * texel + spec;
-                    cr = cg = cb = col;
-                    depth = hz;
+                const float z = P.ws.obj_hz[opix];
+                if (z < hz) {  // strict: on equal depth the earlier object of the joined scene wins
+                    hz = z;
+                    hrec = P.ws.obj_hrec[opix];
+                    hobj = o;
                 }
-                float* __restrict__ ob = P.out.obs + (size_t)env * 4 * S * S + pix;
-                ob[0] = cr;
-                ob[(size_t)S * S] = cg;
-                ob[(size_t)2 * S * S] = cb;
-                ob[(size_t)3 * S * S] = depth;
             }
         }
     }
+    const size_t gp = (size_t)yi * S + xi;
+    if (SOFT) {
+        // environment.py:373: image = i1*i2 + i2*i3 + i1*i3 ; RGB of every silhouette is 1
+        const float I = alpha[0] * alpha[1] + alpha[1] * alpha[2] + alpha[0] * alpha[2];
+        float lsum = live ? I * I : 0.f, ge = 0.f, ga = 0.f;
+        if (GRAD && live) {
+            const float g0 = alpha[1] + alpha[2], g1 = alpha[0] + alpha[2], g2 = alpha[0] + alpha[1];
+            ge = 2.0f * I * (g0 * dae[0] + g1 * dae[1] + g2 * dae[2]);
+            ga = 2.0f * I * (g0 * daa[0] + g1 * daa[1] + g2 * daa[2]);
+        }
+        lsum = wave_sum(lsum);
+        if (GRAD) {
+            ge = wave_sum(ge);
+            ga = wave_sum(ga);
+        }
+        if (lane == 0) {
+            s_red[wave][0] = lsum;
+            s_red[wave][1] = ge;
+            s_red[wave][2] = ga;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float a = 0.f, b = 0.f, c = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                a += s_red[w][0];
+                b += s_red[w][1];
+                c += s_red[w][2];
+            }
+            reinterpret_cast<float4*>(P.ws.partials)[blockIdx.x] = make_float4(a, b, c, 0.f);
+        }
+        if (live) {
+            if (P.out.full_state)
+                reinterpret_cast<float4*>(P.out.full_state)[(size_t)env * S * S + gp] = make_float4(3.f, 3.f, 3.f, I);
+            if (P.out.alphas) {
+                float* __restrict__ al = P.out.alphas + (size_t)env * 3 * S * S + gp;
+                al[0] = alpha[0];
+                al[(size_t)S * S] = alpha[1];
+                al[(size_t)2 * S * S] = alpha[2];
+            }
+        }
+    }
+    if (HARD && live) {
+        // [P3D] HardFlatShader + hard_rgb_blend; depth in channel 3 (environment.py:378)
+        float cr = 1.f, cg = 1.f, cb = 1.f, depth = -1.f;
+        if (hrec >= 0) {
+            const int eo = env * 3 + hobj;
+            const float* __restrict__ r = P.ws.rec + ((size_t)eo * cap + hrec) * OCC_REC_STRIDE;
+            const int fid = __float_as_int(r[R_ID]);
+            const int mesh = P.sc.scene_mesh[eo];
+            const int vo = P.sc.mesh_vert_off[mesh], fo = P.sc.mesh_face_off[mesh];
+            const float ox = P.sc.scene_offset[eo * 3], oy = P.sc.scene_offset[eo * 3 + 1], oz = P.sc.scene_offset[eo * 3 + 2];
+            float w[3][3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int vi = P.sc.pool_faces[(size_t)(fo + fid) * 3 + k];
+                const float* pv = P.sc.pool_verts + (size_t)(vo + vi) * 3;
+                w[k][0] = pv[0] + ox;
+                w[k][1] = pv[1] + oy;
+                w[k][2] = pv[2] + oz;
+            }
+            const float ax = w[1][0] - w[0][0], ay = w[1][1] - w[0][1], az = w[1][2] - w[0][2];
+            const float bx = w[2][0] - w[0][0], by = w[2][1] - w[0][1], bz = w[2][2] - w[0][2];
+            float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+            float nn = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), kShadeEps);
+            nx /= nn; ny /= nn; nz /= nn;
+            nn = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), kShadeEps);  // F.normalize again in diffuse()/specular()
+            nx /= nn; ny /= nn; nz /= nn;
+            const float ccx = (w[0][0] + w[1][0] + w[2][0]) / 3.0f, ccy = (w[0][1] + w[1][1] + w[2][1]) / 3.0f,
+                        ccz = (w[0][2] + w[1][2] + w[2][2]) / 3.0f;
+            float lx = kLightX - ccx, ly = kLightY - ccy, lz = kLightZ - ccz;
+            const float ln = fmaxf(sqrtf(lx * lx + ly * ly + lz * lz), kShadeEps);
+            lx /= ln; ly /= ln; lz /= ln;
+            const float cosang = nx * lx + ny * ly + nz * lz;
+            const float diffuse = kDiffuse * fmaxf(cosang, 0.f);
+            const float* __restrict__ cm = P.cam + (size_t)env * OCC_CAM_STRIDE;
+            float vx = cm[C_C] - ccx, vy = cm[C_C + 1] - ccy, vz = cm[C_C + 2] - ccz;
+            const float vn = fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), kShadeEps);
+            vx /= vn; vy /= vn; vz /= vn;
+            const float rx = -lx + 2.f * (cosang * nx), ry = -ly + 2.f * (cosang * ny), rz = -lz + 2.f * (cosang * nz);
+            float sa = fmaxf(vx * rx + vy * ry + vz * rz, 0.f) * (cosang > 0.f ? 1.f : 0.f);
+            sa *= sa; sa *= sa; sa *= sa; sa *= sa; sa *= sa; sa *= sa;  // ^64
+            const float spec = kSpecular * sa;
+            // texel: white TexturesVertex interpolated with the (unclipped) barycentrics
+            const float fS = (float)S;
+            const float xf = -1.0f + (2.0f * (float)(S - 1 - xi) + 1.0f) / fS;
+            const float yf = -1.0f + (2.0f * (float)(S - 1 - yi) + 1.0f) / fS;
+            const float x0 = r[R_X0], y0 = r[R_Y0], z0 = r[R_Z0], x1 = r[R_X1], y1 = r[R_Y1], z1 = r[R_Z1];
+            const float x2 = r[R_X2], y2 = r[R_Y2], z2 = r[R_Z2];
+            const float ia = r[R_INV_AREA];
+            const float b0 = ((xf - x1) * (y2 - y1) - (yf - y1) * (x2 - x1)) * ia;
+            const float b1 = ((yf - y2) * (x2 - x0) - (xf - x2) * (y2 - y0)) * ia;
+            const float b2 = ((xf - x0) * (y1 - y0) - (yf - y0) * (x1 - x0)) * ia;
+            const float w0 = b0 * z1 * z2, w1 = z0 * b1 * z2, w2 = z0 * z1 * b2;
+            const float den = fmaxf(w0 + w1 + w2, kEpsilon);
+            const float texel = w0 / den + w1 / den + w2 / den;
+            const float col = (kAmbient + diffuse) * texel + spec;
+            cr = cg = cb = col;
+            depth = hz;
+        }
+        float* __restrict__ ob = P.out.obs + (size_t)env * 4 * S * S + gp;
+        ob[0] = cr;
+        ob[(size_t)S * S] = cg;
+        ob[(size_t)2 * S * S] = cb;
+        ob[(size_t)3 * S * S] = depth;
     }
 }
 
@@ -1125,6 +1265,14 @@ extern "C" int occ_profile_read(double* ms_sum, int* launches) {
     return OCC_OK;
 }
 
+#ifdef OCC_DBG_STATS
+extern "C" int occ_debug_stats(unsigned long long* out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(occ::g_dbg_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return 2;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(occ::g_dbg_stats), z, sizeof(z)) == hipSuccess ? 0 : 2;
+}
+#endif
+
 extern "C" int occ_device_cu_count(void) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -1147,14 +1295,19 @@ extern "C" int occ_workspace_query(const OccScene* scene, int n_slots, OccWorksp
         n_slots = (cus > 0 ? cus : 256) * 8;
     }
     const size_t N = (size_t)scene->n_env, cap = (size_t)scene->rec_cap;
-    const size_t ntx = (size_t)scene->img / OCC_TILE;
     out->rec_bytes = N * 3 * cap * OCC_REC_STRIDE * sizeof(float);
-    out->rec_bbox_bytes = N * 3 * cap * sizeof(uint32_t);
+    out->rec_bbox_bytes = N * 3 * cap * 2 * sizeof(uint32_t);
     out->nrec_bytes = N * 3 * sizeof(int32_t);
     out->objrect_bytes = N * 3 * 4 * sizeof(int32_t);
     out->queue_bytes = 16 * sizeof(uint32_t);
     out->lists_bytes = (size_t)n_slots * OCC_LIST_CAP * 64 * (4 * sizeof(float) + sizeof(uint32_t));
-    out->partials_bytes = N * ntx * ntx * 4 * sizeof(float);
+    const size_t S2 = (size_t)scene->img * scene->img;
+    out->partials_bytes = N * ((S2 + 255) / 256) * 4 * sizeof(float);
+    out->offsets_bytes = (N * 3 + 1) * sizeof(int32_t);
+    out->obj_alpha_bytes = N * 3 * S2 * sizeof(float);
+    out->obj_grad_bytes = N * 3 * S2 * 2 * sizeof(float);
+    out->obj_hz_bytes = N * 3 * S2 * sizeof(float);
+    out->obj_hrec_bytes = N * 3 * S2 * sizeof(int32_t);
     out->status_bytes = N * sizeof(int32_t);
     out->n_slots = n_slots;
     return OCC_OK;
@@ -1176,7 +1329,8 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
                           int flags, int faces_per_pixel, void* stream) {
     if (!scene_ok(scene) || !cam || !ws || !out) return OCC_ERR_ARG;
     if (!ws->rec || !ws->rec_bbox || !ws->nrec || !ws->objrect || !ws->queue || !ws->lists || !ws->partials ||
-        !ws->status || ws->n_slots <= 0)
+        !ws->status || !ws->offsets || !ws->obj_alpha || !ws->obj_grad || !ws->obj_hz || !ws->obj_hrec ||
+        ws->n_slots <= 0)
         return OCC_ERR_ARG;
     const bool soft = flags & OCC_RENDER_SOFT, hard = flags & OCC_RENDER_HARD, grad = flags & OCC_RENDER_GRAD;
     if (!soft && !hard) return OCC_ERR_ARG;
@@ -1191,34 +1345,44 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
     else
         hipLaunchKernelGGL(occ_setup_kernel<false>, dim3(N * 3), dim3(256), 0, st, *scene, cam, *ws);
     if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
-    TileParams P;
+    RasterParams P;
     P.sc = *scene;
     P.ws = *ws;
     P.out = *out;
     P.cam = cam;
     P.K = faces_per_pixel;
     P.ntx = scene->img / OCC_TILE;
+    hipLaunchKernelGGL(occ_scan_kernel, dim3(1), dim3(1024), 0, st, ws->objrect, ws->nrec, ws->offsets, N * 3);
+    if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
     const dim3 grid(ws->n_slots), block(64);
     const bool prof = g_prof_on && g_prof_n < kProfMax;
     if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_n], st);
+    const int bpe = (scene->img * scene->img + 255) / 256;
+    const dim3 cgrid(N * bpe), cblock(256);
+#define OCC_LAUNCH(SOFT_, HARD_, GRAD_)                                                             \
+    do {                                                                                            \
+        hipLaunchKernelGGL((occ_raster_kernel<SOFT_, HARD_, GRAD_>), grid, block, 0, st, P);        \
+        if (prof) {                                                                                 \
+            (void)hipEventRecord(g_prof_ev[2 * g_prof_n + 1], st);                                  \
+            g_prof_nenv[g_prof_n] = N;                                                              \
+            g_prof_n += 1;                                                                          \
+        }                                                                                           \
+        hipLaunchKernelGGL((occ_combine_kernel<SOFT_, HARD_, GRAD_>), cgrid, cblock, 0, st, P, bpe); \
+    } while (0)
     if (soft && hard && grad)
-        hipLaunchKernelGGL((occ_tile_kernel<true, true, true>), grid, block, 0, st, P);
+        OCC_LAUNCH(true, true, true);
     else if (soft && hard)
-        hipLaunchKernelGGL((occ_tile_kernel<true, true, false>), grid, block, 0, st, P);
+        OCC_LAUNCH(true, true, false);
     else if (soft && grad)
-        hipLaunchKernelGGL((occ_tile_kernel<true, false, true>), grid, block, 0, st, P);
+        OCC_LAUNCH(true, false, true);
     else if (soft)
-        hipLaunchKernelGGL((occ_tile_kernel<true, false, false>), grid, block, 0, st, P);
+        OCC_LAUNCH(true, false, false);
     else
-        hipLaunchKernelGGL((occ_tile_kernel<false, true, false>), grid, block, 0, st, P);
-    if (prof) {
-        (void)hipEventRecord(g_prof_ev[2 * g_prof_n + 1], st);
-        g_prof_nenv[g_prof_n] = N;
-        g_prof_n += 1;
-    }
+        OCC_LAUNCH(false, true, false);
+#undef OCC_LAUNCH
     if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
     if (soft && (out->loss || out->grad_elaz)) {
-        hipLaunchKernelGGL(occ_reduce_kernel, dim3(N), dim3(64), 0, st, ws->partials, P.ntx * P.ntx, out->loss,
+        hipLaunchKernelGGL(occ_reduce_kernel, dim3(N), dim3(64), 0, st, ws->partials, bpe, out->loss,
                            grad ? out->grad_elaz : nullptr);
         if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
     }

@@ -58,7 +58,7 @@ class OcclusionEngine:
         self.N = int(n_env)
         self.S = int(img_size)
         self.K = int(faces_per_pixel)
-        self.waves_per_cu = int(waves_per_cu or os.environ.get("OCC_WAVES_PER_CU", 10))
+        self.waves_per_cu = int(waves_per_cu or os.environ.get("OCC_WAVES_PER_CU", 11))
         d = self.device
         f32 = dict(dtype=torch.float32, device=d)
         N = self.N
@@ -122,7 +122,9 @@ class OcclusionEngine:
 
         t = dict(rec=buf(sizes.rec_bytes), rec_bbox=buf(sizes.rec_bbox_bytes), nrec=buf(sizes.nrec_bytes),
                  objrect=buf(sizes.objrect_bytes), queue=buf(sizes.queue_bytes), lists=buf(sizes.lists_bytes),
-                 partials=buf(sizes.partials_bytes), status=buf(sizes.status_bytes))
+                 partials=buf(sizes.partials_bytes), status=buf(sizes.status_bytes), offsets=buf(sizes.offsets_bytes),
+                 obj_alpha=buf(sizes.obj_alpha_bytes), obj_grad=buf(sizes.obj_grad_bytes),
+                 obj_hz=buf(sizes.obj_hz_bytes), obj_hrec=buf(sizes.obj_hrec_bytes))
         ws = nat.OccWorkspace()
         for k, v in t.items():
             setattr(ws, k, v.data_ptr())
