@@ -49,7 +49,8 @@ extern "C" {
 /* layout constants shared with the host */
 #define OCC_CAM_STRIDE 48  /* floats per env in the camera buffer */
 #define OCC_REC_STRIDE 36  /* floats per projected-face record (nine 16-byte parts) */
-#define OCC_TILE 8         /* pixels per tile side: one wave64 owns an 8x8 tile */
+#define OCC_TILE 8         /* image sides must be a multiple of this */
+#define OCC_BLOCK 4        /* pixels per block side: one wave64 work item = 4x4 pixels x 4 face slots */
 #ifndef OCC_LIST_CAP
 #define OCC_LIST_CAP 512   /* per-pixel candidate list capacity; a full list is compacted in place to its K nearest */
 #endif
@@ -84,7 +85,7 @@ typedef struct OccWorkspace {
     float* rec;         /* (n_env,3,rec_cap,OCC_REC_STRIDE) projected face records */
     uint32_t* rec_bbox; /* (n_env,3,rec_cap,2) conservative pixel bbox: xl|yl<<16, xh|yh<<16 */
     int32_t* nrec;      /* (n_env,3) */
-    int32_t* objrect;   /* (n_env,3,4) tile rect tx0,ty0,tx1,ty1 (inclusive) */
+    int32_t* objrect;   /* (n_env,3,4) block rect bx0,by0,bx1,by1 (inclusive, OCC_BLOCK-pixel units) */
     uint32_t* queue;    /* (16) work-queue head (zeroed by occ_render) */
     float* lists;       /* (n_slots,OCC_LIST_CAP,64,4) f32 payload rows, then (n_slots,OCC_LIST_CAP,64) u32 key rows */
     float* partials;    /* (n_env,ceil(S*S/256),4) per-block loss / gradient partial sums */

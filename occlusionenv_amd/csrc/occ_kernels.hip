@@ -9,10 +9,10 @@
 //                       (MeshRasterizer.transform), z-clip (clip_faces), cull, per-face record
 //                       with NDC verts + tangents + invariants, ORDERED compaction (face order is
 //                       PyTorch3D's tie-break order), packed tile bbox, object tile rect
-//   occ_scan_kernel     prefix sum of the rect areas -> work items (env, object, tile inside the rect)
-//   occ_raster_kernel   persistent wave64 per work item; the 8x8 tile is cut into four 4x4 quadrants that
-//                       each stream their own face list (on-the-fly binning by ballot over pixel bboxes,
-//                       records staged in LDS by cooperative 16-B loads): soft silhouette (K nearest-z
+//   occ_scan_kernel     prefix sum of the rect areas -> work items (env, object, block inside the rect)
+//   occ_raster_kernel   persistent wave64 per work item (env, object, 4x4-pixel block): 16 pixels x 4 face
+//                       slots per wave (on-the-fly binning by ballot over pixel bboxes, records staged in
+//                       LDS by cooperative 16-B loads): soft silhouette (K nearest-z
 //                       sigmoid product) + hard nearest face of ONE object in one sweep, candidate K-buffer
 //                       (z, 1-p, grad) streamed to HBM/L2 in 1-KiB coalesced rows, exact top-K-by-z
 //                       selection (LDS-histogram radix select) when a pixel has more than K candidates
@@ -284,10 +284,10 @@ __device__ __forceinline__ bool finish_tri(Tri& t, int S) {
     xh = min(xh, S - 1);
     yh = min(yh, S - 1);
     if (xl > xh || yl > yh) return false;
-    t.tx0 = xl / OCC_TILE;
-    t.tx1 = xh / OCC_TILE;
-    t.ty0 = yl / OCC_TILE;
-    t.ty1 = yh / OCC_TILE;
+    t.tx0 = xl / OCC_BLOCK;
+    t.tx1 = xh / OCC_BLOCK;
+    t.ty0 = yl / OCC_BLOCK;
+    t.ty1 = yh / OCC_BLOCK;
     t.bbox = make_uint2((uint32_t)xl | ((uint32_t)yl << 16), (uint32_t)xh | ((uint32_t)yh << 16));
     return true;
 }
@@ -595,34 +595,45 @@ __device__ __forceinline__ uint32_t zkey(float z) {
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
-// Exact top-K-by-z over one lane's candidate list (entries e = 0..cnt-1, in face order; key row e at
-// keys[e*64 + lane], payload (z, 1-p, g_el, g_az) at list[e*64 + lane]).  Keeps the K smallest
-// (z, then earlier entry) like [P3D]'s (pz, face) ordering.
+// combine a per-lane value over the four lanes that share a pixel (lanes l, l+16, l+32, l+48)
+__device__ __forceinline__ int px_sum_i(int v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
+__device__ __forceinline__ float px_sum_f(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
+__device__ __forceinline__ float px_prod_f(float v) { v *= __shfl_xor(v, 16, 64); v *= __shfl_xor(v, 32, 64); return v; }
+__device__ __forceinline__ uint32_t px_min_u(uint32_t v) { v = min(v, (uint32_t)__shfl_xor((int)v, 16, 64)); v = min(v, (uint32_t)__shfl_xor((int)v, 32, 64)); return v; }
+__device__ __forceinline__ uint32_t px_max_u(uint32_t v) { v = max(v, (uint32_t)__shfl_xor((int)v, 16, 64)); v = max(v, (uint32_t)__shfl_xor((int)v, 32, 64)); return v; }
+__device__ __forceinline__ bool px_any(bool v) { return px_sum_i(v ? 1 : 0) != 0; }
+
+// Exact top-K-by-z for one PIXEL whose candidates sit in the lists of its four lanes (lane g = lane >> 4 holds
+// the candidates of faces g, g+4, ... in face order; key row e at keys[e*64 + lane], payload
+// (z, 1-p, g_el, g_az) at list[e*64 + lane]).  Keeps the K smallest z like [P3D]'s (pz, face) ordering
+// (SURVEY A.4); exact-z ties at the boundary are granted to lane 0 first, then 1, 2, 3, each in face order.
 //
-// The list lives in HBM/L2 (it does not fit LDS at 12 waves/CU), so the selection is organised to touch it
-// as little as possible: a most-significant-digit radix select, 5 bits per level, whose per-lane 32-bucket
-// histogram sits in LDS (u16 counters, lane stride 17 dwords = conflict-free when lanes agree).  Each level
-// is one coalesced sweep over the 4-byte key rows; the window [L, L + 32<<sh) starts at the lane's own
-// [kmin, kmax] range, so two levels resolve 10 bits below the first differing bit - typically enough.
-// The last sweep reads the payload rows once and takes every key below the boundary bucket plus the first
-// `need` keys inside it (all of it unless keys tie exactly).  Lanes with active == false idle.
-// COMPACT: also moves the kept entries to the front of the list (stable) for the in-loop overflow case.
+// The lists live in HBM/L2 (they do not fit LDS at 11 waves/CU), so the selection touches them as little as
+// possible: a most-significant-digit radix select, 5 bits per level.  Every lane histograms its OWN key rows
+// into a private 32-bucket u16 histogram in LDS (lane stride 17 dwords = conflict-free when lanes agree); the
+// four histograms of a pixel are summed with two cross-lane adds while they are scanned, so the four lanes
+// take identical decisions.  The window [L, L + 32<<sh) starts at the pixel's own [kmin, kmax] key range: two
+// levels resolve 10 bits below the first differing bit - typically enough.  Key sweeps are pipelined 8 rows
+// deep.  The last sweep reads the payload rows once and takes every key below the boundary bucket plus this
+// lane's share of the keys inside it.  Pixels with active == false idle.
+// COMPACT: also moves the kept entries to the front of each list (stable) and returns the new own count.
 template <bool COMPACT>
-__device__ __forceinline__ void topk_select(float4* __restrict__ list, uint32_t* __restrict__ keys,
-                                            uint32_t* __restrict__ hist, int lane, int cnt, int K, bool active,
-                                            uint32_t kmin, uint32_t kmax, float& pr, float& se, float& sa,
-                                            uint32_t& Tmax) {
+__device__ __forceinline__ void topk_select4(float4* __restrict__ list, uint32_t* __restrict__ keys,
+                                             uint32_t* __restrict__ hist, int lane, int cnt, int K, bool active,
+                                             uint32_t kmin_own, uint32_t kmax_own, float& pr, float& se, float& sa,
+                                             uint32_t& Tmax, int& kept) {
     const int maxc = wave_max_i(active ? cnt : 0);
     uint32_t* __restrict__ h = hist + lane * 17;
+    const uint32_t kmin = px_min_u(kmin_own), kmax = px_max_u(kmax_own);
     uint32_t L = kmin;
-    const uint32_t range = kmax - kmin;
+    const uint32_t range = kmax >= kmin ? kmax - kmin : 0u;
     int sh = range ? max(0, (32 - __builtin_clz(range)) - 5) : 0;
     int need = K;
+    int m_own = 0, mstar_px = 0;
     bool done = !active;
     while (__ballot(!done)) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) h[i] = 0u;
-        // key rows are swept 8 at a time: eight independent loads in flight per lane instead of one
         for (int e0 = 0; e0 < maxc; e0 += 8) {
             uint32_t kk[8];
 #pragma unroll
@@ -640,20 +651,25 @@ __device__ __forceinline__ void topk_select(float4* __restrict__ list, uint32_t*
                 }
             }
         }
-        int cum = 0, bstar = 31, mstar = 0, cumb = 0;
+        int cum = 0, bstar = 31, mstar = 0, cumb = 0, mown = 0;
         bool found = false;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const uint32_t w = h[i];
+            const uint32_t wo = h[i];
+            uint32_t w = wo;  // joint histogram of the pixel: the four private ones added up
+            w += (uint32_t)__shfl_xor((int)w, 16, 64);
+            w += (uint32_t)__shfl_xor((int)w, 32, 64);
             const int c0 = (int)(w & 0xFFFFu), c1 = (int)(w >> 16);
-            if (!found && cum + c0 >= need) { found = true; bstar = 2 * i; mstar = c0; cumb = cum; }
+            if (!found && cum + c0 >= need) { found = true; bstar = 2 * i; mstar = c0; cumb = cum; mown = (int)(wo & 0xFFFFu); }
             cum += c0;
-            if (!found && cum + c1 >= need) { found = true; bstar = 2 * i + 1; mstar = c1; cumb = cum; }
+            if (!found && cum + c1 >= need) { found = true; bstar = 2 * i + 1; mstar = c1; cumb = cum; mown = (int)(wo >> 16); }
             cum += c1;
         }
         if (!done) {
             need -= cumb;
             L += (uint32_t)bstar << sh;
+            m_own = mown;
+            mstar_px = mstar;
             if (mstar == need || sh == 0 || !found) {
                 done = true;
             } else {
@@ -661,8 +677,17 @@ __device__ __forceinline__ void topk_select(float4* __restrict__ list, uint32_t*
             }
         }
     }
-    // final sweep: keys below L, then the first `need` keys of the boundary bucket [L, L + 2^sh)
-    int take = need, w = 0;
+    // this lane's share of the boundary bucket [L, L + 2^sh): all of it when the whole bucket is taken, else
+    // (exact ties) lanes are served in order 0, 1, 2, 3
+    const int g = lane >> 4, base = lane & 15;
+    int before = 0;
+#pragma unroll
+    for (int gg = 0; gg < 3; ++gg) {
+        const int mo = __shfl(m_own, base + 16 * gg, 64);
+        if (gg < g) before += mo;
+    }
+    int take = (mstar_px == need) ? m_own : min(m_own, max(0, need - before));
+    int w = 0;
     pr = 1.0f;
     se = 0.f;
     sa = 0.f;
@@ -702,12 +727,13 @@ __device__ __forceinline__ void topk_select(float4* __restrict__ list, uint32_t*
                 if (COMPACT) {
                     list[(size_t)w * 64 + lane] = vv[i];
                     keys[(size_t)w * 64 + lane] = kk[i];
-                    w += 1;
                 }
+                w += 1;
             }
         }
     }
-    Tmax = tmax;
+    Tmax = px_max_u(tmax);
+    kept = w;
 }
 
 #ifdef OCC_DBG_STATS  // diagnostic build only: loop trip counts of the raster kernel
@@ -766,18 +792,19 @@ __global__ __launch_bounds__(1024) void occ_scan_kernel(const int* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// raster kernel: one persistent wave64 per work item (env, object, 8x8 tile inside the object's rect)
+// raster kernel: one persistent wave64 per work item (env, object, 4x4-pixel block inside the object's rect)
 // ------------------------------------------------------------------------------------------
-// Lane layout: the tile is cut into four 4x4 QUADRANTS; quadrant q owns lanes 16q..16q+15.  Every quadrant
-// streams its OWN list of faces (those whose pixel bbox touches it), so one loop iteration evaluates four
-// different faces - a face whose footprint (~5x5 px with the blur margin) covers a quarter of the tile no
-// longer costs a 64-lane pass.  A pixel belongs to exactly one quadrant and each quadrant visits its faces
-// in index order, so the per-pixel candidate order (PyTorch3D's tie-break) is unchanged.
+// Lane layout: lane = 16 g + l.  l = pixel of the block (x = l & 3, y = l >> 2); g = FACE SLOT: one loop
+// iteration evaluates four different faces (slots 4 it + g of the staged hit list) at the 16 pixels of the
+// block, so a face whose footprint (~5x5 px with the blur margin) is about the size of the block no longer
+// costs a 64-lane pass.  Every pixel's candidates are therefore spread over four lanes (each in face order):
+// counts, products, tangent sums and the nearest hard face are folded across the four lanes at the end of the
+// item, and the exact top-K selection works on the four lists jointly (topk_select4).
 template <bool SOFT, bool HARD, bool GRAD>
 __global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
     const int lane = threadIdx.x;
-    const int q = lane >> 4, l = lane & 15;
-    const int px = (q & 1) * 4 + (l & 3), py = (q >> 1) * 4 + (l >> 2);
+    const int g = lane >> 4, l = lane & 15;
+    const int px = l & 3, py = l >> 2;
     const int S = P.sc.img;
     const int M = P.sc.n_env * 3;
     const float fS = (float)S;
@@ -789,12 +816,12 @@ __global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
                                                                 (size_t)gridDim.x * OCC_LIST_CAP * 64) +
                                     (size_t)blockIdx.x * OCC_LIST_CAP * 64;
     __shared__ uint32_t s_hist[64 * 17];
-    // face records of the current 64-face chunk that touch this tile, staged by cooperative 16-B loads
+    // records of the faces that touch this block, gathered over as many 64-face chunks as fit, staged by
+    // cooperative 16-B loads (one memory round trip per <= 64 staged faces)
     constexpr int kParts = GRAD ? 9 : (SOFT ? 6 : 4);  // float4 parts of a record that this variant reads
-    __shared__ float4 s_stage[64 * 9];
-    __shared__ int s_hit[64];
-    // s_qlist[q][i] = (staged slot << 8 | chunk bit) of the i-th face of quadrant q in the current chunk
-    __shared__ unsigned short s_qlist[4][64];
+    constexpr int kStage = 64;
+    __shared__ float4 s_stage[kStage * 9];
+    __shared__ int s_hit[kStage];  // record index of every staged face
     ciptr offs = as_const(P.ws.offsets);
     const int total_items = offs[M];
 
@@ -813,43 +840,43 @@ __global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
         const int local = item - offs[eo];
         ciptr rect = as_const(P.ws.objrect + eo * 4);
         const int rw = rect[2] - rect[0] + 1;
-        const int ty = rect[1] + local / rw, tx = rect[0] + local % rw;
-        const int xi = tx * OCC_TILE + px, yi = ty * OCC_TILE + py;
+        const int by = rect[1] + local / rw, bx = rect[0] + local % rw;
+        const int x0b = bx * OCC_BLOCK, y0b = by * OCC_BLOCK;
+        const int xi = x0b + px, yi = y0b + py;
         // [P3D] pixel centre in NDC, +X left, +Y up
         const float xf = -1.0f + (2.0f * (float)(S - 1 - xi) + 1.0f) / fS;
         const float yf = -1.0f + (2.0f * (float)(S - 1 - yi) + 1.0f) / fS;
         const int n = as_const(P.ws.nrec + eo)[0];
         OCC_STAT(0, 1);              // work items
-#ifdef OCC_DBG_STATS
-        int dbg_p0 = 0, dbg_p1 = 0, dbg_p2 = 0, dbg_p3 = 0;
-#endif
         OCC_STAT(5, (n + 63) / 64);  // chunks scanned
         const float* __restrict__ recs = P.ws.rec + (size_t)eo * cap * OCC_REC_STRIDE;
         const uint2* __restrict__ bbs = reinterpret_cast<const uint2*>(P.ws.rec_bbox) + (size_t)eo * cap;
 
         float hz = 3.0e38f;
-        int hrec = -1;
-        int count = 0;
+        int hrec = 0x7FFFFFFF;
+        int count = 0;          // candidates in THIS lane's list
         float prod = 1.0f, sge = 0.f, sga = 0.f;
-        bool thr_on = false;   // set once this lane's list has been compacted to its K nearest
-        uint32_t thrT = 0;     // key of the K-th nearest so far: later candidates need key < thrT
-        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;  // key range of the stored candidates
-        Cand pend;             // first half of a clipped pair waiting for its partner
-        bool pend_on = false;
-        int pend_j = -2;       // record index of the waiting half
-        pend.cand = false; pend.inside = false; pend.z = pend.zh = pend.ad = 0.f; pend.q = 1.f; pend.ge = pend.ga = 0.f; pend.amin = 0;
+        bool thr_on = false;    // set once the pixel's lists have been compacted to its K nearest
+        uint32_t thrT = 0;      // key of the K-th nearest so far: later candidates need key < thrT
+        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;  // key range of this lane's stored candidates
+
+        auto touches = [&](uint2 bb) {
+            const int rx0 = bb.x & 0xFFFF, ry0 = bb.x >> 16, rx1 = bb.y & 0xFFFF, ry1 = bb.y >> 16;
+            return (rx0 <= x0b + OCC_BLOCK - 1) && (rx1 >= x0b) && (ry0 <= y0b + OCC_BLOCK - 1) && (ry1 >= y0b);
+        };
 
         auto commit = [&](bool cnd, float z, float qv, float ge, float ga) {
             const uint32_t key = zkey(z);
             bool acc = cnd && (!thr_on || key < thrT);
             if (__ballot(acc && count >= OCC_LIST_CAP)) {
-                // rare: a pixel collected OCC_LIST_CAP candidates -> keep its K nearest, go on
-                const bool full = count >= OCC_LIST_CAP;
+                // rare: a lane's list is full -> keep the pixel's K nearest (over its four lists), go on
+                const bool full = px_any(count >= OCC_LIST_CAP);
                 float pr, se, sa;
                 uint32_t T;
-                topk_select<true>(mylist, mykeys, s_hist, lane, count, K, full, kmin, kmax, pr, se, sa, T);
+                int kept;
+                topk_select4<true>(mylist, mykeys, s_hist, lane, count, K, full, kmin, kmax, pr, se, sa, T, kept);
                 if (full) {
-                    count = K;
+                    count = kept;
                     thr_on = true;
                     thrT = T;
                     kmax = T;
@@ -870,140 +897,149 @@ __global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
             }
         };
 
-        // pixel rectangles of the four quadrants (wave-uniform)
-        const int tx8 = tx * OCC_TILE, ty8 = ty * OCC_TILE;
-        uint2 bb_next = make_uint2(0xFFFFu, 0u);
-        if (lane < n) bb_next = bbs[lane];
-        for (int c0 = 0; c0 < n; c0 += 64) {
-            const uint2 bb = bb_next;
-            bb_next = make_uint2(0xFFFFu, 0u);  // x0 = 65535 > any pixel: never overlaps
-            if (c0 + 64 + lane < n) bb_next = bbs[c0 + 64 + lane];
-            const int rx0 = bb.x & 0xFFFF, ry0 = bb.x >> 16, rx1 = bb.y & 0xFFFF, ry1 = bb.y >> 16;
-            const bool hx0 = (rx0 <= tx8 + 3) && (rx1 >= tx8), hx1 = (rx0 <= tx8 + 7) && (rx1 >= tx8 + 4);
-            const bool hy0 = (ry0 <= ty8 + 3) && (ry1 >= ty8), hy1 = (ry0 <= ty8 + 7) && (ry1 >= ty8 + 4);
-            unsigned long long m0 = __ballot(hx0 && hy0), m1 = __ballot(hx1 && hy0);
-            unsigned long long m2 = __ballot(hx0 && hy1), m3 = __ballot(hx1 && hy1);
-            const unsigned long long mu = m0 | m1 | m2 | m3;
-            if (!mu) continue;
-            const int nh = __popcll(mu);
-            const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-            if ((mu >> lane) & 1ull) {
-                const int myslot = __popcll(mu & lt);
-                s_hit[myslot] = lane;
-                const unsigned short ent = (unsigned short)((myslot << 8) | lane);
-                if ((m0 >> lane) & 1ull) s_qlist[0][__popcll(m0 & lt)] = ent;
-                if ((m1 >> lane) & 1ull) s_qlist[1][__popcll(m1 & lt)] = ent;
-                if ((m2 >> lane) & 1ull) s_qlist[2][__popcll(m2 & lt)] = ent;
-                if ((m3 >> lane) & 1ull) s_qlist[3][__popcll(m3 & lt)] = ent;
-            }
+        int nst = 0;  // staged faces (wave-uniform)
+        auto process_staged = [&]() {
             __syncthreads();
 #ifndef OCC_DBG_NO_STAGE  // timing experiment only
-            for (int idx = lane; idx < nh * kParts; idx += 64) {
+            for (int idx = lane; idx < nst * kParts; idx += 64) {
                 const int k = idx / kParts, part = idx - k * kParts;
-                const int j = c0 + s_hit[k];
-                s_stage[k * 9 + part] = reinterpret_cast<const float4*>(recs + (size_t)j * OCC_REC_STRIDE)[part];
+                s_stage[k * 9 + part] = reinterpret_cast<const float4*>(recs + (size_t)s_hit[k] * OCC_REC_STRIDE)[part];
             }
 #endif
             __syncthreads();
-            const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
-            const int nq = (q == 0) ? n0 : ((q == 1) ? n1 : ((q == 2) ? n2 : n3));
-            int niter = max(max(n0, n1), max(n2, n3));
-            OCC_STAT(1, 1);                  // chunks with at least one hit
-            OCC_STAT(2, nh);                 // staged records
-            OCC_STAT(3, niter);              // eval iterations
-            OCC_STAT(4, n0 + n1 + n2 + n3);  // (face, quadrant) pairs
-#ifdef OCC_DBG_STATS
-            dbg_p0 += n0; dbg_p1 += n1; dbg_p2 += n2; dbg_p3 += n3;
-#endif
+            int niter = (nst + 3) >> 2;
+            OCC_STAT(1, 1);      // staging rounds
+            OCC_STAT(2, nst);    // staged records = (face, block) pairs
+            OCC_STAT(3, niter);  // eval iterations
 #ifdef OCC_DBG_NO_EVAL  // timing experiment only
             niter = 0;
 #endif
             for (int it = 0; it < niter; ++it) {
-                // the it-th face of this lane's quadrant -> its staged slot and chunk bit
-                const bool active = it < nq;
-                const int ent = active ? (int)s_qlist[q][it] : 0;
-                const int slot = ent >> 8, jb = ent & 0xFF;
-                const int j = c0 + jb;
-                const float4* rs = &s_stage[(active ? slot : 0) * 9];
+                const int slot = 4 * it + g;
+                bool active = slot < nst;
+                const int sidx = active ? slot : 0;
+                const int j = s_hit[sidx];
+                const float4* rs = &s_stage[sidx * 9];
                 Cand c1;
                 eval_face<SOFT, GRAD>(OCC_REC_LOAD(rs, kParts), xf, yf, c1);
+                const int flags = active ? __float_as_int(rs[2].z) : 0;
+                // Clipped quad split in two: the pair is resolved where its SECOND half is visited.
+                // A FIRST half whose partner also touches the block is skipped here; a SECOND half whose partner
+                // touches the block evaluates the partner too and keeps one of them.
+                if (__ballot(flags & (FLAG_PAIR_FIRST | FLAG_PAIR_SECOND))) {
+                    const bool is_first = (flags & FLAG_PAIR_FIRST) != 0, is_second = (flags & FLAG_PAIR_SECOND) != 0;
+                    bool partner = false;
+                    if (is_first && j + 1 < n) partner = touches(bbs[j + 1]);
+                    if (is_second && j >= 1) partner = touches(bbs[j - 1]);
+                    if (is_first && partner) active = false;
+                    if (__ballot(is_second && partner)) {
+                        const float4* r1 = reinterpret_cast<const float4*>(recs + (size_t)(is_second && partner ? j - 1 : j) *
+                                                                          OCC_REC_STRIDE);
+                        Cand cf;
+                        eval_face<SOFT, GRAD>(OCC_REC_LOAD(r1, kParts), xf, yf, cf);
+                        if (is_second && partner) {
+                            if (HARD) {
+                                if (cf.inside && (cf.zh < hz || (cf.zh == hz && j - 1 < hrec))) {
+                                    hz = cf.zh;
+                                    hrec = j - 1;
+                                }
+                            }
+                            // [P3D]: the second half replaces the first iff its |d| is strictly smaller.  If both
+                            // are closest to the diagonal they share (t1: edge (v1,v2), t2: edge (v0,v1)) the
+                            // distances are equal in exact arithmetic: keep the first.
+                            const bool shared_tie = (cf.amin == 2) && (c1.amin == 0);
+                            const bool take2 = c1.cand && (!cf.cand || (!shared_tie && c1.ad < cf.ad));
+                            if (!take2) {
+                                const bool ins = c1.inside;
+                                const float zh1 = c1.zh;
+                                c1 = cf;
+                                c1.inside = ins;  // the hard pass still sees the second half itself
+                                c1.zh = zh1;
+                            }
+                        }
+                    }
+                }
                 c1.cand = c1.cand && active;
                 c1.inside = c1.inside && active;
                 if (HARD) {
-                    if (c1.inside && c1.zh < hz) {
+                    if (c1.inside && (c1.zh < hz || (c1.zh == hz && j < hrec))) {
                         hz = c1.zh;
                         hrec = j;
                     }
                 }
-                if (SOFT) {
-                    const int flags = active ? __float_as_int(rs[2].z) : 0;
-                    const bool is_second = ((flags & FLAG_PAIR_SECOND) != 0) && pend_on && (j == pend_j + 1);
-                    // a waiting first half whose partner is not the face at hand goes in on its own
-                    const bool flush = pend_on && !is_second && active;
-                    if (__ballot(flush)) {
-                        commit(flush && pend.cand, pend.z, pend.q, pend.ge, pend.ga);
-                        if (flush) pend_on = false;
-                    }
-                    if (__ballot(pend_on && is_second)) {
-                        // [P3D]: the second half replaces the first iff its |d| is strictly smaller.  If both are
-                        // closest to the diagonal they share (t1: edge (v1,v2), t2: edge (v0,v1)) the distances
-                        // are equal in exact arithmetic: keep the first.
-                        if (pend_on && is_second) {
-                            const bool shared_tie = (pend.amin == 2) && (c1.amin == 0);
-                            const bool take2 = c1.cand && (!pend.cand || (!shared_tie && c1.ad < pend.ad));
-                            if (!take2) c1 = pend;
-                            pend_on = false;
-                        }
-                    }
-                    const bool is_first = (flags & FLAG_PAIR_FIRST) != 0;
-                    if (__ballot(is_first)) {
-                        if (is_first) {
-                            pend = c1;
-                            pend_on = true;
-                            pend_j = j;
-                            c1.cand = false;
-                        }
-                    }
-                    commit(c1.cand, c1.z, c1.q, c1.ge, c1.ga);
-                }
+                if (SOFT) commit(c1.cand, c1.z, c1.q, c1.ge, c1.ga);
             }
             __syncthreads();
+            nst = 0;
+        };
+
+        uint2 bb_next = make_uint2(0xFFFFu, 0u);  // x0 = 65535 > any pixel: never overlaps
+        if (lane < n) bb_next = bbs[lane];
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const uint2 bb = bb_next;
+            bb_next = make_uint2(0xFFFFu, 0u);
+            if (c0 + 64 + lane < n) bb_next = bbs[c0 + 64 + lane];
+            const bool hit = touches(bb);
+            const unsigned long long mask = __ballot(hit);
+            if (!mask) continue;
+            const int cnt = __popcll(mask);
+            if (nst + cnt > kStage) process_staged();
+            const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            if (hit) s_hit[nst + __popcll(mask & lt)] = c0 + lane;
+            nst += cnt;
         }
-#ifdef OCC_DBG_STATS
-        OCC_STAT(6, max(max(dbg_p0, dbg_p1), max(dbg_p2, dbg_p3)));  // iterations if quadrants streamed freely
-#endif
+        if (nst > 0) process_staged();
+
+        // ---- fold the four lanes of every pixel ---------------------------------------------------------
         const size_t opix = ((size_t)eo * S + yi) * S + xi;
         if (SOFT) {
-            if (__ballot(pend_on)) {
-                commit(pend_on && pend.cand, pend.z, pend.q, pend.ge, pend.ga);
-                pend_on = false;
-            }
-            // more than K candidates: keep the K nearest in z (ties: earlier face first), SURVEY A.4
+            const int ctot = px_sum_i(count);
 #ifdef OCC_DBG_NO_TOPK  // timing experiment only: skip the exact selection (results wrong where count > K)
             const bool ovf = false;
 #else
-            const bool ovf = (count > K) || thr_on;
+            const bool ovf = (ctot > K) || px_any(thr_on);
 #endif
             if (__ballot(ovf)) {
+                // more than K candidates: keep the K nearest in z, SURVEY A.4
                 float pr, se, sa;
                 uint32_t T;
-                topk_select<false>(mylist, mykeys, s_hist, lane, count, K, ovf, kmin, kmax, pr, se, sa, T);
+                int kept;
+                topk_select4<false>(mylist, mykeys, s_hist, lane, count, K, ovf, kmin, kmax, pr, se, sa, T, kept);
                 if (ovf) {
                     prod = pr;
                     sge = se;
                     sga = sa;
                 }
             }
-            P.ws.obj_alpha[opix] = 1.0f - prod;
+            prod = px_prod_f(prod);
             if (GRAD) {
-                // d alpha/d theta = -(A/sigma) * sum_k p_k d(d_k)/d theta   
-                const float coef = -prod * kInvSigma;
-                reinterpret_cast<float2*>(P.ws.obj_grad)[opix] = make_float2(coef * sge, coef * sga);
+                sge = px_sum_f(sge);
+                sga = px_sum_f(sga);
+            }
+            if (g == 0) {
+                P.ws.obj_alpha[opix] = 1.0f - prod;
+                if (GRAD) {
+                    // d alpha/d theta = -(A/sigma) * sum_k p_k d(d_k)/d theta   
+                    const float coef = -prod * kInvSigma;
+                    reinterpret_cast<float2*>(P.ws.obj_grad)[opix] = make_float2(coef * sge, coef * sga);
+                }
             }
         }
         if (HARD) {
-            P.ws.obj_hz[opix] = hz;
-            P.ws.obj_hrec[opix] = hrec;
+            // nearest face over the four lanes; equal depth -> smaller record (= face) index, like (pz, f) order
+#pragma unroll
+            for (int m = 16; m <= 32; m <<= 1) {
+                const float oz = __shfl_xor(hz, m, 64);
+                const int orr = __shfl_xor(hrec, m, 64);
+                if (oz < hz || (oz == hz && orr < hrec)) {
+                    hz = oz;
+                    hrec = orr;
+                }
+            }
+            if (g == 0) {
+                P.ws.obj_hz[opix] = hz;
+                P.ws.obj_hrec[opix] = (hrec == 0x7FFFFFFF) ? -1 : hrec;
+            }
         }
     }
 }
@@ -1020,7 +1056,7 @@ __global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bp
     const int pix = blk * 256 + tid;
     const bool live = pix < S * S;
     const int yi = live ? pix / S : 0, xi = live ? pix - (pix / S) * S : 0;
-    const int tx = xi / OCC_TILE, ty = yi / OCC_TILE;
+    const int tx = xi / OCC_BLOCK, ty = yi / OCC_BLOCK;
     const int cap = P.sc.rec_cap;
     float alpha[3] = {0.f, 0.f, 0.f}, dae[3] = {0.f, 0.f, 0.f}, daa[3] = {0.f, 0.f, 0.f};
     float hz = 3.0e38f;
