@@ -91,6 +91,7 @@ typedef struct OccWorkspace {
     float* partials;    /* (n_env,ceil(S*S/256),4) per-block loss / gradient partial sums */
     int32_t* status;    /* (n_env) OCC_STATUS_* bits, OR-ed in; caller clears */
     int32_t* offsets;   /* (n_env*3+1) first work item of every (env, object) */
+    uint32_t* rec_cbox; /* (n_env,3,ceil(rec_cap/64),2) union pixel bbox of every 64-record chunk */
     float* obj_alpha;   /* (n_env,3,S,S) per-object silhouette alpha, valid inside the object's tile rect */
     float* obj_grad;    /* (n_env,3,S,S,2) d alpha / d(el, az) */
     float* obj_hz;      /* (n_env,3,S,S) depth of the nearest face of the object (3e38 = none) */
@@ -101,7 +102,7 @@ typedef struct OccWorkspace {
 typedef struct OccWorkspaceSizes {
     size_t rec_bytes, rec_bbox_bytes, nrec_bytes, objrect_bytes, queue_bytes, lists_bytes,
         partials_bytes, status_bytes, offsets_bytes, obj_alpha_bytes, obj_grad_bytes, obj_hz_bytes,
-        obj_hrec_bytes;
+        obj_hrec_bytes, rec_cbox_bytes;
     int32_t n_slots; /* recommended persistent-wave count for this device */
 } OccWorkspaceSizes;
 

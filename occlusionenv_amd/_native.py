@@ -53,6 +53,7 @@ class OccWorkspace(C.Structure):
         ("partials", C.c_void_p),
         ("status", C.c_void_p),
         ("offsets", C.c_void_p),
+        ("rec_cbox", C.c_void_p),
         ("obj_alpha", C.c_void_p),
         ("obj_grad", C.c_void_p),
         ("obj_hz", C.c_void_p),
@@ -76,6 +77,7 @@ class OccWorkspaceSizes(C.Structure):
         ("obj_grad_bytes", C.c_size_t),
         ("obj_hz_bytes", C.c_size_t),
         ("obj_hrec_bytes", C.c_size_t),
+        ("rec_cbox_bytes", C.c_size_t),
         ("n_slots", C.c_int32),
     ]
 

@@ -464,6 +464,26 @@ __global__ __launch_bounds__(256) void occ_setup_kernel(OccScene sc, const float
         __syncthreads();
     }
     if (overflow) atomicOr(&ws.status[env], OCC_STATUS_REC_OVERFLOW);
+    {
+        // union pixel bbox of every 64-record chunk: lets the raster kernel skip whole chunks (two-level scan)
+        const int nr = min(total, sc.rec_cap);
+        const int nch = (nr + 63) >> 6;
+        uint2* __restrict__ cbx = reinterpret_cast<uint2*>(ws.rec_cbox) + (size_t)eo * ((sc.rec_cap + 63) >> 6);
+        for (int c = wave; c < nch; c += 4) {
+            const int j = c * 64 + lane;
+            uint2 bb = make_uint2(0xFFFFFFFFu, 0u);
+            if (j < nr) bb = bbs[j];
+            int xl = bb.x & 0xFFFF, yl = bb.x >> 16, xh = bb.y & 0xFFFF, yh = bb.y >> 16;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                xl = min(xl, __shfl_xor(xl, m, 64));
+                yl = min(yl, __shfl_xor(yl, m, 64));
+                xh = max(xh, __shfl_xor(xh, m, 64));
+                yh = max(yh, __shfl_xor(yh, m, 64));
+            }
+            if (lane == 0) cbx[c] = make_uint2((uint32_t)xl | ((uint32_t)yl << 16), (uint32_t)xh | ((uint32_t)yh << 16));
+        }
+    }
     if (tid == 0) {
         ws.nrec[eo] = min(total, sc.rec_cap);
         ws.objrect[eo * 4 + 0] = s_rect[0];
@@ -848,7 +868,6 @@ __global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
         const float yf = -1.0f + (2.0f * (float)(S - 1 - yi) + 1.0f) / fS;
         const int n = as_const(P.ws.nrec + eo)[0];
         OCC_STAT(0, 1);              // work items
-        OCC_STAT(5, (n + 63) / 64);  // chunks scanned
         const float* __restrict__ recs = P.ws.rec + (size_t)eo * cap * OCC_REC_STRIDE;
         const uint2* __restrict__ bbs = reinterpret_cast<const uint2*>(P.ws.rec_bbox) + (size_t)eo * cap;
 
@@ -882,6 +901,7 @@ __global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
                     kmax = T;
                     acc = cnd && (key < thrT);
                 }
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): leave no load pending across the hot loop
             }
             if (acc) {
 #ifndef OCC_DBG_NO_STORE  // timing experiment only
@@ -958,6 +978,7 @@ __global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
                             }
                         }
                     }
+                    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): leave no load pending across the hot loop
                 }
                 c1.cand = c1.cand && active;
                 c1.inside = c1.inside && active;
@@ -973,20 +994,45 @@ __global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
             nst = 0;
         };
 
-        uint2 bb_next = make_uint2(0xFFFFu, 0u);  // x0 = 65535 > any pixel: never overlaps
-        if (lane < n) bb_next = bbs[lane];
-        for (int c0 = 0; c0 < n; c0 += 64) {
-            const uint2 bb = bb_next;
-            bb_next = make_uint2(0xFFFFu, 0u);
-            if (c0 + 64 + lane < n) bb_next = bbs[c0 + 64 + lane];
-            const bool hit = touches(bb);
+        // two-level scan: chunk boxes (one lane per 64-record chunk) -> candidate chunks -> their record boxes,
+        // the next candidate chunk's row of boxes being fetched while the current one is processed
+        const int nch = (n + 63) >> 6;
+        const uint2* __restrict__ cbx = reinterpret_cast<const uint2*>(P.ws.rec_cbox) + (size_t)eo * ((cap + 63) >> 6);
+        const uint2 kEmptyBox = make_uint2(0xFFFFu, 0u);  // x0 = 65535 > any pixel: never overlaps
+        int cwin = -64;
+        unsigned long long cmask = 0;
+        auto next_chunk = [&]() -> int {
+            while (!cmask) {
+                cwin += 64;
+                if (cwin >= nch) return -1;
+                uint2 cb = kEmptyBox;
+                if (cwin + lane < nch) cb = cbx[cwin + lane];
+                cmask = __ballot(touches(cb));
+            }
+            const int bit = __builtin_ctzll(cmask);
+            cmask &= cmask - 1;
+            return cwin + bit;
+        };
+        int c = next_chunk();
+        uint2 bb_cur = kEmptyBox;
+        if (c >= 0 && c * 64 + lane < n) bb_cur = bbs[c * 64 + lane];
+        while (c >= 0) {
+            const int cn = next_chunk();
+            uint2 bb_nxt = kEmptyBox;
+            if (cn >= 0 && cn * 64 + lane < n) bb_nxt = bbs[cn * 64 + lane];
+            const int c0 = c * 64;
+            const bool hit = touches(bb_cur);
             const unsigned long long mask = __ballot(hit);
-            if (!mask) continue;
-            const int cnt = __popcll(mask);
-            if (nst + cnt > kStage) process_staged();
-            const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-            if (hit) s_hit[nst + __popcll(mask & lt)] = c0 + lane;
-            nst += cnt;
+            OCC_STAT(5, 1);  // chunk rows scanned
+            if (mask) {
+                const int cnt = __popcll(mask);
+                if (nst + cnt > kStage) process_staged();
+                const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+                if (hit) s_hit[nst + __popcll(mask & lt)] = c0 + lane;
+                nst += cnt;
+            }
+            c = cn;
+            bb_cur = bb_nxt;
         }
         if (nst > 0) process_staged();
 
@@ -1333,6 +1379,7 @@ extern "C" int occ_workspace_query(const OccScene* scene, int n_slots, OccWorksp
     const size_t N = (size_t)scene->n_env, cap = (size_t)scene->rec_cap;
     out->rec_bytes = N * 3 * cap * OCC_REC_STRIDE * sizeof(float);
     out->rec_bbox_bytes = N * 3 * cap * 2 * sizeof(uint32_t);
+    out->rec_cbox_bytes = N * 3 * ((cap + 63) / 64) * 2 * sizeof(uint32_t);
     out->nrec_bytes = N * 3 * sizeof(int32_t);
     out->objrect_bytes = N * 3 * 4 * sizeof(int32_t);
     out->queue_bytes = 16 * sizeof(uint32_t);
@@ -1365,7 +1412,7 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
                           int flags, int faces_per_pixel, void* stream) {
     if (!scene_ok(scene) || !cam || !ws || !out) return OCC_ERR_ARG;
     if (!ws->rec || !ws->rec_bbox || !ws->nrec || !ws->objrect || !ws->queue || !ws->lists || !ws->partials ||
-        !ws->status || !ws->offsets || !ws->obj_alpha || !ws->obj_grad || !ws->obj_hz || !ws->obj_hrec ||
+        !ws->status || !ws->rec_cbox || !ws->offsets || !ws->obj_alpha || !ws->obj_grad || !ws->obj_hz || !ws->obj_hrec ||
         ws->n_slots <= 0)
         return OCC_ERR_ARG;
     const bool soft = flags & OCC_RENDER_SOFT, hard = flags & OCC_RENDER_HARD, grad = flags & OCC_RENDER_GRAD;
