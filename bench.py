@@ -112,6 +112,8 @@ def main():
     # az ~ U(-40, 40) rad (SubProcVecEnv.py:233), which mostly yields non-occluding views that finish at once.
     az0 = (torch.rand(args.envs, generator=torch.Generator().manual_seed(42 + rank)) * 2 - 1) * 0.6
     venv._reset_envs(list(range(args.envs)), az0)
+    if eng.R:
+        venv._warm_reserve()
     dev = eng.device
     gen = torch.Generator(device=dev).manual_seed(7 + rank)
     gathered = torch.empty(world * args.envs, rollout.RECORD_FLOATS, device=dev) if world > 1 else None

@@ -87,7 +87,7 @@ typedef struct OccWorkspace {
     int32_t* nrec;      /* (n_env,3) */
     int32_t* objrect;   /* (n_env,3,4) block rect bx0,by0,bx1,by1 (inclusive, OCC_BLOCK-pixel units) */
     uint32_t* queue;    /* (16) work-queue head (zeroed by occ_render) */
-    float* lists;       /* (n_slots,OCC_LIST_CAP,64,4) f32 payload rows, then (n_slots,OCC_LIST_CAP,64) u32 key rows */
+    float* lists;       /* (n_slots,OCC_LIST_CAP,64,4) per-wave K-buffer rows: (key(z) u32, 1-p, g_el, g_az) per lane */
     float* partials;    /* (n_env,ceil(S*S/256),4) per-block loss / gradient partial sums */
     int32_t* status;    /* (n_env) OCC_STATUS_* bits, OR-ed in; caller clears */
     int32_t* offsets;   /* (n_env*3+1) first work item of every (env, object) */

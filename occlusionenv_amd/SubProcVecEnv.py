@@ -112,12 +112,59 @@ class SimpleVecEnv(VecEnv):
         self.keys, shapes, dtypes = obs_space_info(obs_space)
         self.actions = None
         dev = torch.device(f"cuda:{torch.cuda.current_device()}") if torch.cuda.is_available() else env.device
-        self.engine = OcclusionEngine(shared_pool(dev), self.num_envs, env.img_size, device=dev)
+        # reserve slots: speculative auto-reset scenes rendered inside every batched step (see engine.py)
+        same_data = all(e.shapenet_dataset is env.shapenet_dataset for e in self.envs)
+        reserve = min(64, self.num_envs // 8) if same_data else 0
+        self.engine = OcclusionEngine(shared_pool(dev), self.num_envs, env.img_size, device=dev, reserve=reserve)
         for i, e in enumerate(self.envs):
             e._attach(self.engine, i)
+        self._rs_scene = [None] * reserve   # scene assigned to each reserve slot
+        self._rs_tries = [0] * reserve      # rejection-loop tries spent on the slot's current reset (environment.py:288)
+        self._rs_ready = [False] * reserve  # slot holds an accepted reset scene, rendered by the last step
 
     def step_async(self, actions):
         self.actions = actions
+
+    def _refill_reserve(self, slots):
+        """Draw a new candidate scene for the given reserve slots (host) and upload them in one copy."""
+        if not slots:
+            return
+        from .environment import sample_scene
+
+        ds = self.envs[0].shapenet_dataset
+        pool = self.engine.pool
+        for r in slots:
+            while True:
+                try:
+                    ids, offs = sample_scene(ds, pool)
+                except (IndexError, KeyError, ValueError, OSError):
+                    continue
+                if max(pool.num_faces(m) for m in ids) <= 250000:  # environment.py:296-298
+                    break
+            self._rs_scene[r] = (ids, offs)
+            self._rs_ready[r] = False
+        self.engine.set_reserve_scenes(slots, [self._rs_scene[r][0] for r in slots], [self._rs_scene[r][1] for r in slots])
+
+    def _warm_reserve(self):
+        """Run the reset rejection loop for every reserve slot that does not hold an accepted scene yet (batched,
+        synchronous).  Called from reset() and before the first step so that steady state starts at once; afterwards
+        the loop advances one try per step inside the step launches."""
+        eng, R = self.engine, self.engine.R
+        pending = [r for r in range(R) if not self._rs_ready[r]]
+        self._refill_reserve([r for r in pending if self._rs_scene[r] is None])
+        while pending:
+            res = eng.evaluate_scenes([self._rs_scene[r][0] for r in pending], [self._rs_scene[r][1] for r in pending],
+                                      4.0, 0.0, 0.0)
+            ok = (res["loss"] > 0.1).cpu().tolist()
+            redraw = []
+            for j, r in enumerate(pending):
+                self._rs_tries[r] += 1
+                if ok[j] or self._rs_tries[r] >= 10:
+                    self._rs_ready[r] = True
+                else:
+                    redraw.append(r)
+            self._refill_reserve(redraw)
+            pending = redraw
 
     def step_wait(self):
         eng = self.engine
@@ -126,21 +173,55 @@ class SimpleVecEnv(VecEnv):
             actions = torch.as_tensor(np.asarray(actions), dtype=torch.float32)
         if actions.device != eng.device:
             actions = actions.to(eng.device)
-        obs, rewards, dones, full_state, loss = eng.step(actions)
+        R, N = eng.R, self.num_envs
+        if R and self._rs_scene[0] is None:
+            self._warm_reserve()
+        if R:
+            obs, rewards, dones, full_state, loss, out = eng.step(actions, with_reserve=True)
+            rs_ok = out["loss_all"][N:] > 0.1
+        else:
+            obs, rewards, dones, full_state, loss = eng.step(actions)
+            rs_ok = torch.zeros(0, dtype=torch.bool, device=eng.device)
         infos = _LazyInfos(eng, full_state, loss)
-        # one host sync per batched step: which envs finished + kernel status words
-        flags = torch.stack([dones.any(), eng.status.any()]).cpu()
+        # ONE host sync per batched step: which envs finished, which reserve scenes pass the reset test
+        # (loss > 0.1, environment.py:327), kernel status words
+        flags = torch.cat([dones.any()[None], eng.status.any()[None], rs_ok]).cpu()
         if bool(flags[1]):
             eng.check_status()
+        if R:
+            ok = flags[2:].tolist()
+            redraw = []
+            for r in range(R):  # every slot was rendered by this launch with its current scene
+                if self._rs_ready[r]:
+                    continue
+                self._rs_tries[r] += 1
+                if ok[r] or self._rs_tries[r] >= 10:  # accept, or keep the 10th try regardless (environment.py:327)
+                    self._rs_ready[r] = True
+                else:
+                    redraw.append(r)
+            self._refill_reserve(redraw)
         if bool(flags[0]):
-            # save final observation where user can get it, then reset (SubProcVecEnv.py:211-214); all
-            # finished envs are reset together (one batched render per rejection round)
-            fin = torch.nonzero(dones).reshape(-1)
-            term = obs[fin].clone()
-            fin_l = fin.tolist()
+            # save final observation where user can get it, then reset (SubProcVecEnv.py:211-214)
+            fin_l = torch.nonzero(dones).reshape(-1).tolist()
+            term = obs[fin_l].clone()
             for j, i in enumerate(fin_l):
                 infos.set(i, "terminal_observation", term[j:j + 1])
-            obs[fin] = self._reset_envs(fin_l, torch.zeros(len(fin_l)))[:, 0]
+            take, left = [], []
+            ready = [r for r in range(R) if self._rs_ready[r]]
+            for i in fin_l:
+                if ready:
+                    take.append((i, ready.pop()))
+                else:
+                    left.append(i)
+            if take:
+                eng.commit_from_reserve([i for i, _ in take], [r for _, r in take], out)
+                for i, r in take:
+                    self.envs[i]._scene = self._rs_scene[r]
+                    self.envs[i].image = out["full_state_all"][N + r:N + r + 1]
+                    self._rs_tries[r] = 0
+                self._refill_reserve([r for _, r in take])
+            if left:  # reserve exhausted: synchronous batched reset for the rest
+                obs[left] = self._reset_envs(left, torch.zeros(len(left)))[:, 0]
         return obs, rewards, dones, infos
 
     def seed(self, seed=None):
@@ -204,7 +285,10 @@ class SimpleVecEnv(VecEnv):
 
     def reset(self):
         az = [np.random.default_rng().uniform(low=-40, high=40) for _ in range(self.num_envs)]
-        return self._reset_envs(list(range(self.num_envs)), az)
+        obs = self._reset_envs(list(range(self.num_envs)), az)
+        if self.engine.R:
+            self._warm_reserve()
+        return obs
 
     def close(self):
         for env in self.envs:

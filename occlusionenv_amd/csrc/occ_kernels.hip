@@ -624,8 +624,8 @@ __device__ __forceinline__ uint32_t px_max_u(uint32_t v) { v = max(v, (uint32_t)
 __device__ __forceinline__ bool px_any(bool v) { return px_sum_i(v ? 1 : 0) != 0; }
 
 // Exact top-K-by-z for one PIXEL whose candidates sit in the lists of its four lanes (lane g = lane >> 4 holds
-// the candidates of faces g, g+4, ... in face order; key row e at keys[e*64 + lane], payload
-// (z, 1-p, g_el, g_az) at list[e*64 + lane]).  Keeps the K smallest z like [P3D]'s (pz, face) ordering
+// the candidates of faces g, g+4, ... in face order; entry e = (key(z), 1-p, g_el, g_az) at list[e*64 + lane],
+// the key being the order-preserving integer image of z).  Keeps the K smallest z like [P3D]'s (pz, face) ordering
 // (SURVEY A.4); exact-z ties at the boundary are granted to lane 0 first, then 1, 2, 3, each in face order.
 //
 // The lists live in HBM/L2 (they do not fit LDS at 11 waves/CU), so the selection touches them as little as
@@ -638,12 +638,14 @@ __device__ __forceinline__ bool px_any(bool v) { return px_sum_i(v ? 1 : 0) != 0
 // lane's share of the keys inside it.  Pixels with active == false idle.
 // COMPACT: also moves the kept entries to the front of each list (stable) and returns the new own count.
 template <bool COMPACT>
-__device__ __forceinline__ void topk_select4(float4* __restrict__ list, uint32_t* __restrict__ keys,
-                                             uint32_t* __restrict__ hist, int lane, int cnt, int K, bool active,
+__device__ __forceinline__ void topk_select4(float4* __restrict__ list, uint32_t* __restrict__ hist, int lane,
+                                             int cnt, int K, bool active,
                                              uint32_t kmin_own, uint32_t kmax_own, float& pr, float& se, float& sa,
                                              uint32_t& Tmax, int& kept) {
     const int maxc = wave_max_i(active ? cnt : 0);
     uint32_t* __restrict__ h = hist + lane * 17;
+    // the key is component x of the 16-byte row entry: row e of this lane sits 256 dwords further on
+    const uint32_t* __restrict__ keyp = reinterpret_cast<const uint32_t*>(list) + lane * 4;
     const uint32_t kmin = px_min_u(kmin_own), kmax = px_max_u(kmax_own);
     uint32_t L = kmin;
     const uint32_t range = kmax >= kmin ? kmax - kmin : 0u;
@@ -659,7 +661,7 @@ __device__ __forceinline__ void topk_select4(float4* __restrict__ list, uint32_t
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int e = e0 + i;
-                kk[i] = (!done && e < cnt) ? keys[(size_t)e * 64 + lane] : 0u;
+                kk[i] = (!done && e < cnt) ? keyp[(size_t)e * 256] : 0u;
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -719,7 +721,7 @@ __device__ __forceinline__ void topk_select4(float4* __restrict__ list, uint32_t
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int e = e0 + i;
-            kk[i] = (active && e < cnt) ? keys[(size_t)e * 64 + lane] : 0xFFFFFFFFu;
+            kk[i] = (active && e < cnt) ? keyp[(size_t)e * 256] : 0xFFFFFFFFu;
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -744,10 +746,7 @@ __device__ __forceinline__ void topk_select4(float4* __restrict__ list, uint32_t
                 se += vv[i].z;
                 sa += vv[i].w;
                 tmax = max(tmax, kk[i]);
-                if (COMPACT) {
-                    list[(size_t)w * 64 + lane] = vv[i];
-                    keys[(size_t)w * 64 + lane] = kk[i];
-                }
+                if (COMPACT) list[(size_t)w * 64 + lane] = vv[i];
                 w += 1;
             }
         }
@@ -830,11 +829,8 @@ __global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
     const float fS = (float)S;
     const int cap = P.sc.rec_cap;
     const int K = P.K;
-    // per-wave K-buffer: payload rows (float4) for every slot first, then the compact key rows
+    // per-wave K-buffer: OCC_LIST_CAP rows of 64 lane entries (key(z), 1-p, g_el, g_az), 16 B each
     float4* __restrict__ mylist = reinterpret_cast<float4*>(P.ws.lists) + (size_t)blockIdx.x * OCC_LIST_CAP * 64;
-    uint32_t* __restrict__ mykeys = reinterpret_cast<uint32_t*>(reinterpret_cast<float4*>(P.ws.lists) +
-                                                                (size_t)gridDim.x * OCC_LIST_CAP * 64) +
-                                    (size_t)blockIdx.x * OCC_LIST_CAP * 64;
     __shared__ uint32_t s_hist[64 * 17];
     // records of the faces that touch this block, gathered over as many 64-face chunks as fit, staged by
     // cooperative 16-B loads (one memory round trip per <= 64 staged faces)
@@ -893,7 +889,7 @@ __global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
                 float pr, se, sa;
                 uint32_t T;
                 int kept;
-                topk_select4<true>(mylist, mykeys, s_hist, lane, count, K, full, kmin, kmax, pr, se, sa, T, kept);
+                topk_select4<true>(mylist, s_hist, lane, count, K, full, kmin, kmax, pr, se, sa, T, kept);
                 if (full) {
                     count = kept;
                     thr_on = true;
@@ -905,8 +901,9 @@ __global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
             }
             if (acc) {
 #ifndef OCC_DBG_NO_STORE  // timing experiment only
-                mylist[(size_t)count * 64 + lane] = make_float4(z, qv, ge, ga);
-                mykeys[(size_t)count * 64 + lane] = key;
+                // one 16-byte store per candidate; 32-bit offset from the wave-uniform base
+                *reinterpret_cast<float4*>(reinterpret_cast<char*>(mylist) + (uint32_t)(count * 1024 + lane * 16)) =
+                    make_float4(__uint_as_float(key), qv, ge, ga);
 #endif
                 kmin = min(kmin, key);
                 kmax = max(kmax, key);
@@ -1050,7 +1047,7 @@ __global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
                 float pr, se, sa;
                 uint32_t T;
                 int kept;
-                topk_select4<false>(mylist, mykeys, s_hist, lane, count, K, ovf, kmin, kmax, pr, se, sa, T, kept);
+                topk_select4<false>(mylist, s_hist, lane, count, K, ovf, kmin, kmax, pr, se, sa, T, kept);
                 if (ovf) {
                     prod = pr;
                     sge = se;
@@ -1383,7 +1380,7 @@ extern "C" int occ_workspace_query(const OccScene* scene, int n_slots, OccWorksp
     out->nrec_bytes = N * 3 * sizeof(int32_t);
     out->objrect_bytes = N * 3 * 4 * sizeof(int32_t);
     out->queue_bytes = 16 * sizeof(uint32_t);
-    out->lists_bytes = (size_t)n_slots * OCC_LIST_CAP * 64 * (4 * sizeof(float) + sizeof(uint32_t));
+    out->lists_bytes = (size_t)n_slots * OCC_LIST_CAP * 64 * 4 * sizeof(float);
     const size_t S2 = (size_t)scene->img * scene->img;
     out->partials_bytes = N * ((S2 + 255) / 256) * 4 * sizeof(float);
     out->offsets_bytes = (N * 3 + 1) * sizeof(int32_t);

@@ -44,7 +44,7 @@ class OcclusionEngine:
     """State + workspace of N environments on one GPU."""
 
     def __init__(self, pool: MeshPool, n_env: int, img_size: int, device=None, faces_per_pixel: int = 100,
-                 waves_per_cu: Optional[int] = None):
+                 waves_per_cu: Optional[int] = None, reserve: int = 0):
         self.lib = nat.load()
         if not torch.cuda.is_available():
             raise nat.NativeError("OcclusionEngine needs a ROCm GPU (torch.cuda.is_available() is False); "
@@ -62,19 +62,27 @@ class OcclusionEngine:
         d = self.device
         f32 = dict(dtype=torch.float32, device=d)
         N = self.N
-        # environment state (environment.py:302-306,323-324)
-        self.elevation = torch.zeros(N, **f32)
-        self.azimuth = torch.zeros(N, **f32)
-        self.radius = torch.full((N,), 4.0, **f32)
+        # ``reserve`` extra scene slots ride along with every batched step: candidate scenes for the auto-reset
+        # of finished envs, rendered with the reset() camera in the SAME launch sequence (no extra launch, no
+        # extra host sync when an env finishes).  They are invisible through the public (N-sized) views.
+        self.R = int(reserve)
+        NT = self.NT = N + self.R
+        # environment state (environment.py:302-306,323-324); rows N.. belong to the reserve
+        self._el_all = torch.zeros(NT, **f32)
+        self._az_all = torch.zeros(NT, **f32)
+        self._rad_all = torch.full((NT,), 4.0, **f32)
+        self._mesh_all = torch.zeros(NT, 3, dtype=torch.int32, device=d)
+        self._off_all = torch.zeros(NT, 3, 3, **f32)
+        self._cam_all = torch.zeros(NT, nat.CAM_STRIDE, **f32)
+        self._alphas_all = torch.zeros(NT, 3, self.S, self.S, **f32)
+        self.elevation, self.azimuth, self.radius = self._el_all[:N], self._az_all[:N], self._rad_all[:N]
         self.camera_position = torch.zeros(N, 3, **f32)
         self.full_reward = torch.zeros(N, **f32)
         self.object_mass = torch.ones(N, **f32)
         # scene description
-        self.scene_mesh = torch.zeros(N, 3, dtype=torch.int32, device=d)
-        self.scene_offset = torch.zeros(N, 3, 3, **f32)
+        self.scene_mesh, self.scene_offset = self._mesh_all[:N], self._off_all[:N]
         # internal buffers
-        self.cam = torch.zeros(N, nat.CAM_STRIDE, **f32)
-        self.alphas = torch.zeros(N, 3, self.S, self.S, **f32)
+        self.cam, self.alphas = self._cam_all[:N], self._alphas_all[:N]
         self._ws_key = None
         self._ws = None
         self._ws_tensors = None
@@ -105,10 +113,10 @@ class OcclusionEngine:
         return 2 * max(self.pool.max_faces, 1)
 
     def _ensure_workspace(self) -> nat.OccWorkspace:
-        key = (self._rec_cap(), self.N, self.S)
+        key = (self._rec_cap(), self.NT, self.S)
         if self._ws_key == key:
             return self._ws
-        sc = self._scene_struct(self.N, self.scene_mesh, self.scene_offset)
+        sc = self._scene_struct(self.NT, self._mesh_all, self._off_all)
         sizes = nat.OccWorkspaceSizes()
         cus = self.lib.occ_device_cu_count()
         if cus <= 0:
@@ -135,7 +143,7 @@ class OcclusionEngine:
     @property
     def status(self) -> torch.Tensor:
         self._ensure_workspace()
-        return self._ws_tensors["status"][: self.N]
+        return self._ws_tensors["status"][: self.NT]
 
     def check_status(self) -> None:
         """Raise if any kernel reported a data-dependent failure (host sync)."""
@@ -226,7 +234,7 @@ class OcclusionEngine:
         f32 = dict(dtype=torch.float32, device=d)
         smesh = torch.as_tensor(mesh_ids, dtype=torch.int32).reshape(-1, 3).to(d).contiguous()
         m = smesh.shape[0]
-        if m > self.N:
+        if m > self.NT:
             raise ValueError("more candidate scenes than env slots")
         if int(smesh.min()) < 0 or int(smesh.max()) >= len(self.pool):
             raise ValueError("mesh id outside the pool")
@@ -277,8 +285,39 @@ class OcclusionEngine:
         out = self._render(idx, nat.CAM_POSITION, pos, nat.RENDER_HARD)
         return out["obs"]
 
-    def step(self, actions: torch.Tensor, env_ids=None):
-        """Batched step(): returns (obs (n,4,S,S), reward (n,) [autograd-attached], done (n,) bool, full_state, loss)."""
+    def set_reserve_scenes(self, slots, mesh_ids, offsets) -> None:
+        """Assign candidate scenes to reserve slots (rendered with radius 4, az = el = 0: reset()'s defaults,
+        which is what SimpleVecEnv's auto-reset uses, SubProcVecEnv.py:214)."""
+        if not len(slots):
+            return
+        idx = torch.as_tensor(slots, dtype=torch.long, device=self.device).reshape(-1) + self.N
+        m = torch.as_tensor(mesh_ids, dtype=torch.int32).reshape(-1, 3)
+        if int(m.min()) < 0 or int(m.max()) >= len(self.pool):
+            raise ValueError("mesh id outside the pool")
+        self._mesh_all[idx] = m.to(self.device)
+        self._off_all[idx] = torch.as_tensor(offsets, dtype=torch.float32).reshape(-1, 3, 3).to(self.device)
+
+    def commit_from_reserve(self, env_ids, slots, out) -> None:
+        """Install reserve slots (rendered by the last step()) as the fresh reset() state of ``env_ids``."""
+        e = torch.as_tensor(env_ids, dtype=torch.long, device=self.device).reshape(-1)
+        r = torch.as_tensor(slots, dtype=torch.long, device=self.device).reshape(-1) + self.N
+        self._mesh_all[e] = self._mesh_all[r]
+        self._off_all[e] = self._off_all[r]
+        self._rad_all[e] = self._rad_all[r]
+        self._az_all[e] = self._az_all[r]
+        self._el_all[e] = self._el_all[r]
+        self.camera_position[e] = 0.0
+        self._cam_all[e] = self._cam_all[r]
+        self._alphas_all[e] = self._alphas_all[r]
+        loss = out["loss_all"][r]
+        self.full_reward[e] = loss
+        self.object_mass[e] = loss + 1.0
+        out["obs"][e] = out["obs_all"][r]
+
+    def step(self, actions: torch.Tensor, env_ids=None, with_reserve: bool = False):
+        """Batched step(): returns (obs (n,4,S,S), reward (n,) [autograd-attached], done (n,) bool, full_state, loss).
+        ``with_reserve`` (whole-batch steps only) also renders the reserve scenes in the same launch sequence and
+        returns a sixth item: the dict of whole-batch tensors (``obs_all``, ``loss_all`` ...)."""
         idx = None if env_ids is None else torch.as_tensor(env_ids, dtype=torch.long, device=self.device).reshape(-1)
         n = self.N if idx is None else int(idx.numel())
         if actions.shape != (n, 2):
@@ -286,8 +325,12 @@ class OcclusionEngine:
         need_grad = bool(actions.requires_grad and torch.is_grad_enabled())
         a = actions.detach().to(self.device, torch.float32).contiguous()
         flags = nat.RENDER_SOFT | nat.RENDER_HARD | (nat.RENDER_GRAD if need_grad else 0)
-        out = self._render(idx, nat.CAM_STEP, a, flags)
         d = self.device
+        if with_reserve and idx is None and self.R > 0:
+            out = self._render_with_reserve(a, flags)
+        else:
+            with_reserve = False
+            out = self._render(idx, nat.CAM_STEP, a, flags)
         reward = torch.empty(n, dtype=torch.float32, device=d)
         done = torch.empty(n, dtype=torch.uint8, device=d)
         grad_action = torch.empty(n, 2, dtype=torch.float32, device=d) if need_grad else None
@@ -299,4 +342,32 @@ class OcclusionEngine:
             self.full_reward[idx] = fr
         if need_grad:
             reward = _RewardGrad.apply(actions, reward, grad_action)
-        return out["obs"], reward, done.bool(), out["full_state"], out["loss"]
+        res = (out["obs"], reward, done.bool(), out["full_state"], out["loss"])
+        return res + (out,) if with_reserve else res
+
+    def _render_with_reserve(self, actions, flags):
+        """One launch sequence over N stepping envs (OCC_CAM_STEP) + R reserve scenes (OCC_CAM_LOOKAT)."""
+        ws = self._ensure_workspace()
+        d, S, N, NT = self.device, self.S, self.N, self.NT
+        f32 = dict(dtype=torch.float32, device=d)
+        st = self._stream()
+        nat.check(self.lib.occ_camera(nat.CAM_STEP, _p(actions), _p(self._el_all), _p(self._az_all), _p(self._rad_all),
+                                      _p(self._cam_all), _p(self.camera_position), N, st), "occ_camera")
+        nat.check(self.lib.occ_camera(nat.CAM_LOOKAT, None, _p(self._el_all[N:]), _p(self._az_all[N:]),
+                                      _p(self._rad_all[N:]), _p(self._cam_all[N:]), None, self.R, st), "occ_camera")
+        obs = torch.empty(NT, 4, S, S, **f32)
+        fs = torch.empty(NT, S, S, 4, **f32)
+        loss = torch.empty(NT, **f32)
+        ro = nat.OccRenderOut()
+        ro.obs, ro.full_state, ro.loss, ro.alphas = obs.data_ptr(), fs.data_ptr(), loss.data_ptr(), self._alphas_all.data_ptr()
+        out = {}
+        if flags & nat.RENDER_GRAD:
+            g = torch.empty(NT, 2, **f32)
+            ro.grad_elaz = g.data_ptr()
+            out["grad_elaz"] = g[:N]
+        sc = self._scene_struct(NT, self._mesh_all, self._off_all)
+        nat.check(self.lib.occ_render(C.byref(sc), _p(self._cam_all), C.byref(ws), C.byref(ro), flags, self.K, st),
+                  "occ_render")
+        out.update(obs=obs[:N], full_state=fs[:N], loss=loss[:N], cam=self._cam_all, obs_all=obs, loss_all=loss,
+                   full_state_all=fs)
+        return out

@@ -107,6 +107,38 @@ def test_auto_reset_on_done(ds):
             assert "terminal_observation" not in infos[i] and float(rewards[i]) < 4.0
 
 
+def test_auto_reset_from_the_speculative_reserve(ds):
+    """N = 16 -> 2 reserve scenes ride along with every step; a finished env takes one without an extra render.
+    The installed state must be exactly what a synchronous reset() of that scene computes."""
+    from occlusionenv_amd.engine import OcclusionEngine
+    from environment import OcclusionEnv
+    from SubProcVecEnv import SimpleVecEnv
+
+    np.random.seed(2)
+    N, S = 16, 64
+    venv = SimpleVecEnv([lambda: OcclusionEnv(ds, img_size=S) for _ in range(N)])
+    venv.reset()
+    eng = venv.engine
+    assert eng.R == 2 and all(venv._rs_ready)
+    off = eng.scene_offset[5].clone()
+    off[1, 0], off[2, 0] = 50.0, -50.0  # no occlusion left -> env 5 finishes
+    eng.scene_offset[5] = off
+    ready_scenes = [venv._rs_scene[r] for r in range(2)]
+    obs, rewards, dones, infos = venv.step(torch.randn(N, 2, device="cuda"))
+    assert bool(dones[5]) and "terminal_observation" in infos[5]
+    assert venv.envs[5]._scene in ready_scenes  # taken from the reserve
+    ids, offs = venv.envs[5]._scene
+    ref = eng.evaluate_scenes([ids], [offs], 4.0, 0.0, 0.0)
+    assert torch.equal(ref["obs"][0], obs[5])
+    assert float(eng.full_reward[5]) == float(ref["loss"][0]) and float(eng.object_mass[5]) == float(ref["loss"][0] + 1.0)
+    assert float(eng.azimuth[5]) == 0.0 and float(eng.elevation[5]) == 0.0 and float(eng.radius[5]) == 4.0
+    assert float(eng.camera_position[5].abs().sum()) == 0.0
+    assert torch.equal(eng.scene_offset[5].cpu(), torch.tensor(offs, dtype=torch.float32))
+    # the next step runs on the new scene
+    obs2, r2, d2, _ = venv.step(torch.randn(N, 2, device="cuda"))
+    assert torch.isfinite(r2).all()
+
+
 def test_full_size_properties(ds):
     """BASELINE config 3 size (1024 envs, 128x128, ~5k-face meshes): properties that need no oracle."""
     from tests.parity_utils import make_case
