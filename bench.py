@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--img", type=int, default=128)
     ap.add_argument("--workload", default="shapenet5k", choices=["shapenet5k", "mixed", "teapot"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 path on fewer GPUs than ranks (ranks share devices)")
     ap.add_argument("--cpu-sample", type=int, default=16)
     args = ap.parse_args()
 
@@ -96,10 +98,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     import torch.distributed as dist
 
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    if args.dist_backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"rank {local_rank} has no GPU ({ndev} visible); use --dist-backend gloo to rehearse")
+    dev_index = local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"))
+        else:
+            dist.init_process_group("gloo")
 
     from occlusionenv_amd import _native as nat
     from occlusionenv_amd import rollout
@@ -149,7 +158,7 @@ def main():
     eng.check_status()
     assert torch.isfinite(g).all()
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -194,7 +203,7 @@ def main():
                                    + (", + RCCL all-gather of 1044-B rollout records" if world > 1 else ""),
                        "envs_per_gpu": args.envs, "img": args.img, "faces_per_pixel": 100,
                        "sharding": f"env-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "occ_tile_kernel<soft,hard,grad>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "occ_raster_kernel<soft,hard,grad>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_launch, "avg_launch_ms": avg_ms,

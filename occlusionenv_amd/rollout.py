@@ -52,5 +52,11 @@ def all_gather_records(rec: torch.Tensor, out: torch.Tensor = None) -> torch.Ten
     world = dist.get_world_size()
     if out is None:
         out = torch.empty(world * rec.shape[0], rec.shape[1], dtype=rec.dtype, device=rec.device)
+    if dist.get_backend() == "gloo" and rec.is_cuda:
+        # CPU rehearsal of the N>1 path on a box without N GPUs: stage through host memory
+        host = torch.empty(out.shape, dtype=rec.dtype)
+        dist.all_gather_into_tensor(host, rec.detach().cpu().contiguous())
+        out.copy_(host)
+        return out
     dist.all_gather_into_tensor(out, rec.contiguous())
     return out
