@@ -83,7 +83,8 @@ typedef struct OccScene {
 /* Caller-allocated scratch; sizes from occ_workspace_query(). */
 typedef struct OccWorkspace {
     float* rec;         /* (n_env,3,rec_cap,OCC_REC_STRIDE) projected face records */
-    uint32_t* rec_bbox; /* (n_env,3,rec_cap,2) conservative pixel bbox: xl|yl<<16, xh|yh<<16 */
+    uint32_t* rec_bbox; /* (n_env,3,rec_cap,4) per record: pixel bbox xl|yl<<16, xh|yh<<16, key of its nearest vertex depth, 0 */
+    uint32_t* scan;     /* (n_env,3,rec_cap,4) the same rows sorted front to back, .w = record index (the raster scan order) */
     int32_t* nrec;      /* (n_env,3) */
     int32_t* objrect;   /* (n_env,3,4) block rect bx0,by0,bx1,by1 (inclusive, OCC_BLOCK-pixel units) */
     uint32_t* queue;    /* (16) work-queue head (zeroed by occ_render) */
@@ -91,7 +92,7 @@ typedef struct OccWorkspace {
     float* partials;    /* (n_env,ceil(S*S/256),4) per-block loss / gradient partial sums */
     int32_t* status;    /* (n_env) OCC_STATUS_* bits, OR-ed in; caller clears */
     int32_t* offsets;   /* (n_env*3+1) first work item of every (env, object) */
-    uint32_t* rec_cbox; /* (n_env,3,ceil(rec_cap/64),2) union pixel bbox of every 64-record chunk */
+    uint32_t* rec_cbox; /* (n_env,3,ceil(rec_cap/64),4) union pixel bbox + nearest depth key of every 64-entry scan chunk */
     float* obj_alpha;   /* (n_env,3,S,S) per-object silhouette alpha, valid inside the object's tile rect */
     float* obj_grad;    /* (n_env,3,S,S,2) d alpha / d(el, az) */
     float* obj_hz;      /* (n_env,3,S,S) depth of the nearest face of the object (3e38 = none) */
@@ -102,7 +103,7 @@ typedef struct OccWorkspace {
 typedef struct OccWorkspaceSizes {
     size_t rec_bytes, rec_bbox_bytes, nrec_bytes, objrect_bytes, queue_bytes, lists_bytes,
         partials_bytes, status_bytes, offsets_bytes, obj_alpha_bytes, obj_grad_bytes, obj_hz_bytes,
-        obj_hrec_bytes, rec_cbox_bytes;
+        obj_hrec_bytes, rec_cbox_bytes, scan_bytes;
     int32_t n_slots; /* recommended persistent-wave count for this device */
 } OccWorkspaceSizes;
 

@@ -46,6 +46,7 @@ class OccWorkspace(C.Structure):
     _fields_ = [
         ("rec", C.c_void_p),
         ("rec_bbox", C.c_void_p),
+        ("scan", C.c_void_p),
         ("nrec", C.c_void_p),
         ("objrect", C.c_void_p),
         ("queue", C.c_void_p),
@@ -78,6 +79,7 @@ class OccWorkspaceSizes(C.Structure):
         ("obj_hz_bytes", C.c_size_t),
         ("obj_hrec_bytes", C.c_size_t),
         ("rec_cbox_bytes", C.c_size_t),
+        ("scan_bytes", C.c_size_t),
         ("n_slots", C.c_int32),
     ]
 

@@ -257,7 +257,7 @@ __device__ __forceinline__ PVert cut_edge(const VVert& a, const VVert& b) {
 
 struct Tri {
     PVert v[3];
-    uint2 bbox;  // conservative pixel bbox: x = xl | yl << 16, y = xh | yh << 16
+    uint4 bbox;  // conservative pixel bbox x = xl | yl << 16, y = xh | yh << 16; z = key of the smallest vertex depth
     int tx0, ty0, tx1, ty1;
 };
 
@@ -288,12 +288,14 @@ __device__ __forceinline__ bool finish_tri(Tri& t, int S) {
     t.tx1 = xh / OCC_BLOCK;
     t.ty0 = yl / OCC_BLOCK;
     t.ty1 = yh / OCC_BLOCK;
-    t.bbox = make_uint2((uint32_t)xl | ((uint32_t)yl << 16), (uint32_t)xh | ((uint32_t)yh << 16));
+    const uint32_t zb = __float_as_uint(fmin3(t.v[0].z, t.v[1].z, t.v[2].z));
+    t.bbox = make_uint4((uint32_t)xl | ((uint32_t)yl << 16), (uint32_t)xh | ((uint32_t)yh << 16),
+                        (zb & 0x80000000u) ? ~zb : (zb | 0x80000000u), 0u);
     return true;
 }
 
 template <bool GRAD>
-__device__ __forceinline__ void write_record(float* __restrict__ r, uint2* __restrict__ bb, const Tri& t,
+__device__ __forceinline__ void write_record(float* __restrict__ r, uint4* __restrict__ bb, const Tri& t,
                                              int face_id, int flags) {
     const float x0 = t.v[0].x, y0 = t.v[0].y, x1 = t.v[1].x, y1 = t.v[1].y, x2 = t.v[2].x, y2 = t.v[2].y;
     float o[OCC_REC_STRIDE];
@@ -333,6 +335,71 @@ __device__ __forceinline__ void write_record(float* __restrict__ r, uint2* __res
     *bb = t.bbox;
 }
 
+// union pixel bbox and smallest depth key of every 64-entry chunk of the scan order (two-level scan)
+__device__ __forceinline__ void chunk_boxes(const uint4* __restrict__ scan, uint4* __restrict__ cbx, int nr, int wave,
+                                            int lane) {
+    const int nch = (nr + 63) >> 6;
+    for (int c = wave; c < nch; c += 4) {
+        const int j = c * 64 + lane;
+        uint4 bb = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
+        if (j < nr) bb = scan[j];
+        int xl = bb.x & 0xFFFF, yl = bb.x >> 16, xh = bb.y & 0xFFFF, yh = bb.y >> 16;
+        uint32_t zk = bb.z;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            xl = min(xl, __shfl_xor(xl, m, 64));
+            yl = min(yl, __shfl_xor(yl, m, 64));
+            xh = max(xh, __shfl_xor(xh, m, 64));
+            yh = max(yh, __shfl_xor(yh, m, 64));
+            zk = min(zk, (uint32_t)__shfl_xor((int)zk, m, 64));
+        }
+        if (lane == 0)
+            cbx[c] = make_uint4((uint32_t)xl | ((uint32_t)yl << 16), (uint32_t)xh | ((uint32_t)yh << 16), zk, 0u);
+    }
+}
+
+// Objects with many visible faces (>= kSortMin records: a pixel then collects far more than K candidates) get
+// their scan order sorted front to back - bitonic sort of (depth key, record index) in LDS - so that the raster
+// kernel reaches "every pixel of the block holds its K nearest" after the nearest faces and skips the rest.
+constexpr int kSortMin = 4096;
+__global__ __launch_bounds__(256) void occ_sort_kernel(OccScene sc, OccWorkspace ws, int sort_cap) {
+    extern __shared__ unsigned long long s_keys[];  // sort_cap keys: depth key << 32 | record index
+    const int eo = blockIdx.x;
+    const int nr = ws.nrec[eo];
+    if (nr < kSortMin) return;
+    int p2 = 1;
+    while (p2 < nr) p2 <<= 1;
+    if (p2 > sort_cap) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint4* __restrict__ bbs = reinterpret_cast<const uint4*>(ws.rec_bbox) + (size_t)eo * sc.rec_cap;
+    uint4* __restrict__ scan = reinterpret_cast<uint4*>(ws.scan) + (size_t)eo * sc.rec_cap;
+    for (int i = tid; i < p2; i += 256) s_keys[i] = i < nr ? (((unsigned long long)bbs[i].z << 32) | (unsigned)i) : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= p2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < p2; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = s_keys[i], b = s_keys[ixj];
+                    const bool asc = (i & k) == 0;
+                    if ((a > b) == asc) {
+                        s_keys[i] = b;
+                        s_keys[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < nr; i += 256) {
+        const int j = (int)(s_keys[i] & 0xFFFFFFFFu);
+        const uint4 bb = bbs[j];
+        scan[i] = make_uint4(bb.x, bb.y, bb.z, (uint32_t)j);
+    }
+    __syncthreads();
+    chunk_boxes(scan, reinterpret_cast<uint4*>(ws.rec_cbox) + (size_t)eo * ((sc.rec_cap + 63) >> 6), nr, wave, lane);
+}
+
 template <bool GRAD>
 __global__ __launch_bounds__(256) void occ_setup_kernel(OccScene sc, const float* __restrict__ cam, OccWorkspace ws) {
     __shared__ int s_wcnt[4];
@@ -367,7 +434,7 @@ __global__ __launch_bounds__(256) void occ_setup_kernel(OccScene sc, const float
     }
     __syncthreads();
     float* __restrict__ rec = ws.rec + (size_t)eo * sc.rec_cap * OCC_REC_STRIDE;
-    uint2* __restrict__ bbs = reinterpret_cast<uint2*>(ws.rec_bbox) + (size_t)eo * sc.rec_cap;
+    uint4* __restrict__ bbs = reinterpret_cast<uint4*>(ws.rec_bbox) + (size_t)eo * sc.rec_cap;
     int total = 0;
     bool overflow = false;
     for (int base = 0; base < nF; base += 256) {
@@ -465,24 +532,19 @@ __global__ __launch_bounds__(256) void occ_setup_kernel(OccScene sc, const float
     }
     if (overflow) atomicOr(&ws.status[env], OCC_STATUS_REC_OVERFLOW);
     {
-        // union pixel bbox of every 64-record chunk: lets the raster kernel skip whole chunks (two-level scan)
+        // SCAN ORDER of the raster kernel: (pixel bbox, key of the nearest vertex depth, record index) rows, in
+        // face order here (mesh order is spatially coherent, which makes the chunk boxes selective);
+        // occ_sort_kernel re-orders dense objects front to back.  The depth keys make the raster kernel's
+        // pruning exact in ANY order; the order only decides how early it bites.
         const int nr = min(total, sc.rec_cap);
-        const int nch = (nr + 63) >> 6;
-        uint2* __restrict__ cbx = reinterpret_cast<uint2*>(ws.rec_cbox) + (size_t)eo * ((sc.rec_cap + 63) >> 6);
-        for (int c = wave; c < nch; c += 4) {
-            const int j = c * 64 + lane;
-            uint2 bb = make_uint2(0xFFFFFFFFu, 0u);
-            if (j < nr) bb = bbs[j];
-            int xl = bb.x & 0xFFFF, yl = bb.x >> 16, xh = bb.y & 0xFFFF, yh = bb.y >> 16;
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                xl = min(xl, __shfl_xor(xl, m, 64));
-                yl = min(yl, __shfl_xor(yl, m, 64));
-                xh = max(xh, __shfl_xor(xh, m, 64));
-                yh = max(yh, __shfl_xor(yh, m, 64));
-            }
-            if (lane == 0) cbx[c] = make_uint2((uint32_t)xl | ((uint32_t)yl << 16), (uint32_t)xh | ((uint32_t)yh << 16));
+        uint4* __restrict__ scan = reinterpret_cast<uint4*>(ws.scan) + (size_t)eo * sc.rec_cap;
+        __syncthreads();  // bbs[] of the whole object written
+        for (int i = tid; i < nr; i += 256) {
+            const uint4 bb = bbs[i];
+            scan[i] = make_uint4(bb.x, bb.y, bb.z, (uint32_t)i);
         }
+        __syncthreads();
+        chunk_boxes(scan, reinterpret_cast<uint4*>(ws.rec_cbox) + (size_t)eo * ((sc.rec_cap + 63) >> 6), nr, wave, lane);
     }
     if (tid == 0) {
         ws.nrec[eo] = min(total, sc.rec_cap);
@@ -865,7 +927,8 @@ __global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
         const int n = as_const(P.ws.nrec + eo)[0];
         OCC_STAT(0, 1);              // work items
         const float* __restrict__ recs = P.ws.rec + (size_t)eo * cap * OCC_REC_STRIDE;
-        const uint2* __restrict__ bbs = reinterpret_cast<const uint2*>(P.ws.rec_bbox) + (size_t)eo * cap;
+        const uint4* __restrict__ bbs = reinterpret_cast<const uint4*>(P.ws.rec_bbox) + (size_t)eo * cap;
+        const uint4* __restrict__ scan = reinterpret_cast<const uint4*>(P.ws.scan) + (size_t)eo * cap;
 
         float hz = 3.0e38f;
         int hrec = 0x7FFFFFFF;
@@ -873,16 +936,20 @@ __global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
         float prod = 1.0f, sge = 0.f, sga = 0.f;
         bool thr_on = false;    // set once the pixel's lists have been compacted to its K nearest
         uint32_t thrT = 0;      // key of the K-th nearest so far: later candidates need key < thrT
+        bool lim_on = false;    // pixel already holds >= K candidates: limT = their largest key bounds the K-th
+        uint32_t limT = 0;      //   nearest from above, so a later candidate needs key < limT to matter
+        uint32_t thrB = 0xFFFFFFFFu;  // block-wide skip key (wave-uniform): faces whose nearest vertex is not
+                                      // nearer than this can change neither a pixel's K nearest nor its hard face
         uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;  // key range of this lane's stored candidates
 
-        auto touches = [&](uint2 bb) {
+        auto touches = [&](uint4 bb) {
             const int rx0 = bb.x & 0xFFFF, ry0 = bb.x >> 16, rx1 = bb.y & 0xFFFF, ry1 = bb.y >> 16;
             return (rx0 <= x0b + OCC_BLOCK - 1) && (rx1 >= x0b) && (ry0 <= y0b + OCC_BLOCK - 1) && (ry1 >= y0b);
         };
 
         auto commit = [&](bool cnd, float z, float qv, float ge, float ga) {
             const uint32_t key = zkey(z);
-            bool acc = cnd && (!thr_on || key < thrT);
+            bool acc = cnd && (!thr_on || key < thrT) && (!lim_on || key < limT);
             if (__ballot(acc && count >= OCC_LIST_CAP)) {
                 // rare: a lane's list is full -> keep the pixel's K nearest (over its four lists), go on
                 const bool full = px_any(count >= OCC_LIST_CAP);
@@ -989,43 +1056,64 @@ __global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
             }
             __syncthreads();
             nst = 0;
+            // Front-to-back pruning (the scan order is ascending in the faces' nearest vertex depth and a
+            // candidate's depth is never below it).  Once a pixel holds >= K candidates, the largest stored key
+            // bounds its K-th nearest from above -> later candidates at or beyond it are dropped unseen; once this
+            // holds for all 16 pixels, and every pixel has a hard face, faces starting beyond both bounds are
+            // skipped altogether and the item ends at the first such chunk.
+            if (SOFT) {
+                const int ctot = px_sum_i(count);
+                if (!lim_on && ctot >= K) {
+                    lim_on = true;
+                    limT = px_max_u(kmax);
+                }
+            }
+            uint32_t bound = 0xFFFFFFFFu;
+            if (SOFT) bound = lim_on ? (thr_on ? min(limT, thrT) : limT) : 0xFFFFFFFFu;
+            if (HARD) {
+                const uint32_t hk = hz < 3.0e38f ? zkey(hz) : 0xFFFFFFFFu;  // every lane keeps its own nearest so far
+                bound = SOFT ? max(bound, px_min_u(hk)) : px_min_u(hk);
+            }
+            // wave max over the 16 pixels (each pixel's four lanes agree)
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) bound = max(bound, (uint32_t)__shfl_xor((int)bound, m, 64));
+            thrB = (uint32_t)__builtin_amdgcn_readfirstlane((int)bound);
         };
 
         // two-level scan: chunk boxes (one lane per 64-record chunk) -> candidate chunks -> their record boxes,
         // the next candidate chunk's row of boxes being fetched while the current one is processed
         const int nch = (n + 63) >> 6;
-        const uint2* __restrict__ cbx = reinterpret_cast<const uint2*>(P.ws.rec_cbox) + (size_t)eo * ((cap + 63) >> 6);
-        const uint2 kEmptyBox = make_uint2(0xFFFFu, 0u);  // x0 = 65535 > any pixel: never overlaps
+        const uint4* __restrict__ cbx = reinterpret_cast<const uint4*>(P.ws.rec_cbox) + (size_t)eo * ((cap + 63) >> 6);
+        const uint4 kEmptyBox = make_uint4(0xFFFFu, 0u, 0xFFFFFFFFu, 0u);  // x0 = 65535 > any pixel: never overlaps
         int cwin = -64;
         unsigned long long cmask = 0;
         auto next_chunk = [&]() -> int {
             while (!cmask) {
                 cwin += 64;
                 if (cwin >= nch) return -1;
-                uint2 cb = kEmptyBox;
+                uint4 cb = kEmptyBox;
                 if (cwin + lane < nch) cb = cbx[cwin + lane];
-                cmask = __ballot(touches(cb));
+                cmask = __ballot(touches(cb) && cb.z < thrB);
             }
             const int bit = __builtin_ctzll(cmask);
             cmask &= cmask - 1;
             return cwin + bit;
         };
         int c = next_chunk();
-        uint2 bb_cur = kEmptyBox;
-        if (c >= 0 && c * 64 + lane < n) bb_cur = bbs[c * 64 + lane];
+        uint4 bb_cur = kEmptyBox;
+        if (c >= 0 && c * 64 + lane < n) bb_cur = scan[c * 64 + lane];
         while (c >= 0) {
             const int cn = next_chunk();
-            uint2 bb_nxt = kEmptyBox;
-            if (cn >= 0 && cn * 64 + lane < n) bb_nxt = bbs[cn * 64 + lane];
-            const int c0 = c * 64;
-            const bool hit = touches(bb_cur);
+            uint4 bb_nxt = kEmptyBox;
+            if (cn >= 0 && cn * 64 + lane < n) bb_nxt = scan[cn * 64 + lane];
+            const bool hit = touches(bb_cur) && bb_cur.z < thrB;
             const unsigned long long mask = __ballot(hit);
             OCC_STAT(5, 1);  // chunk rows scanned
             if (mask) {
                 const int cnt = __popcll(mask);
                 if (nst + cnt > kStage) process_staged();
                 const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-                if (hit) s_hit[nst + __popcll(mask & lt)] = c0 + lane;
+                if (hit) s_hit[nst + __popcll(mask & lt)] = (int)bb_cur.w;
                 nst += cnt;
             }
             c = cn;
@@ -1375,8 +1463,9 @@ extern "C" int occ_workspace_query(const OccScene* scene, int n_slots, OccWorksp
     }
     const size_t N = (size_t)scene->n_env, cap = (size_t)scene->rec_cap;
     out->rec_bytes = N * 3 * cap * OCC_REC_STRIDE * sizeof(float);
-    out->rec_bbox_bytes = N * 3 * cap * 2 * sizeof(uint32_t);
-    out->rec_cbox_bytes = N * 3 * ((cap + 63) / 64) * 2 * sizeof(uint32_t);
+    out->rec_bbox_bytes = N * 3 * cap * 4 * sizeof(uint32_t);
+    out->scan_bytes = N * 3 * cap * 4 * sizeof(uint32_t);
+    out->rec_cbox_bytes = N * 3 * ((cap + 63) / 64) * 4 * sizeof(uint32_t);
     out->nrec_bytes = N * 3 * sizeof(int32_t);
     out->objrect_bytes = N * 3 * 4 * sizeof(int32_t);
     out->queue_bytes = 16 * sizeof(uint32_t);
@@ -1409,7 +1498,7 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
                           int flags, int faces_per_pixel, void* stream) {
     if (!scene_ok(scene) || !cam || !ws || !out) return OCC_ERR_ARG;
     if (!ws->rec || !ws->rec_bbox || !ws->nrec || !ws->objrect || !ws->queue || !ws->lists || !ws->partials ||
-        !ws->status || !ws->rec_cbox || !ws->offsets || !ws->obj_alpha || !ws->obj_grad || !ws->obj_hz || !ws->obj_hrec ||
+        !ws->status || !ws->rec_cbox || !ws->scan || !ws->offsets || !ws->obj_alpha || !ws->obj_grad || !ws->obj_hz || !ws->obj_hrec ||
         ws->n_slots <= 0)
         return OCC_ERR_ARG;
     const bool soft = flags & OCC_RENDER_SOFT, hard = flags & OCC_RENDER_HARD, grad = flags & OCC_RENDER_GRAD;
@@ -1424,6 +1513,12 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
         hipLaunchKernelGGL(occ_setup_kernel<true>, dim3(N * 3), dim3(256), 0, st, *scene, cam, *ws);
     else
         hipLaunchKernelGGL(occ_setup_kernel<false>, dim3(N * 3), dim3(256), 0, st, *scene, cam, *ws);
+    if (scene->rec_cap >= kSortMin) {
+        // dense objects only: front-to-back scan order (LDS sort buffer: 8192 keys = 64 KiB)
+        const int sort_cap = 8192;
+        hipLaunchKernelGGL(occ_sort_kernel, dim3(N * 3), dim3(256), (size_t)sort_cap * sizeof(unsigned long long), st,
+                           *scene, *ws, sort_cap);
+    }
     if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
     RasterParams P;
     P.sc = *scene;
