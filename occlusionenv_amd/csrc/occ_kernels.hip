@@ -897,7 +897,7 @@ __global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
     // records of the faces that touch this block, gathered over as many 64-face chunks as fit, staged by
     // cooperative 16-B loads (one memory round trip per <= 64 staged faces)
     constexpr int kParts = GRAD ? 9 : (SOFT ? 6 : 4);  // float4 parts of a record that this variant reads
-    constexpr int kStage = 64;
+    constexpr int kStage = 32;  // 32 x 144 B: keeps the wave at ~9 KiB of LDS -> 16 waves per CU
     __shared__ float4 s_stage[kStage * 9];
     __shared__ int s_hit[kStage];  // record index of every staged face
     ciptr offs = as_const(P.ws.offsets);
@@ -1109,12 +1109,22 @@ __global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
             const bool hit = touches(bb_cur) && bb_cur.z < thrB;
             const unsigned long long mask = __ballot(hit);
             OCC_STAT(5, 1);  // chunk rows scanned
-            if (mask) {
-                const int cnt = __popcll(mask);
-                if (nst + cnt > kStage) process_staged();
-                const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-                if (hit) s_hit[nst + __popcll(mask & lt)] = (int)bb_cur.w;
-                nst += cnt;
+            unsigned long long m = mask;
+            const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            while (m) {  // a chunk may hold more hits than the staging buffer has room for
+                const int room = kStage - nst;
+                const int cnt = __popcll(m);
+                const int rank = __popcll(m & lt);
+                const bool mine = (m >> lane) & 1ull;
+                if (mine && rank < room) s_hit[nst + rank] = (int)bb_cur.w;
+                if (cnt <= room) {
+                    nst += cnt;
+                    m = 0;
+                } else {
+                    nst = kStage;
+                    m = __ballot(mine && rank >= room);
+                    process_staged();
+                }
             }
             c = cn;
             bb_cur = bb_nxt;
