@@ -151,6 +151,26 @@ int occ_step_finish(const float* loss, const float* grad_elaz, const float* cam,
                     float* grad_action, int n_env, void* stream);
 
 /*
+ * Host hand-off of SimpleVecEnv.step_wait (SubProcVecEnv.py:209-218): one int32 buffer
+ *   flags[0..n_env) = done, flags[n_env..n_env+n_reserve) = reserve scene passes reset()'s acceptance test
+ *   (loss > 0.1, environment.py:327), flags[n_env+n_reserve] = some status word is non-zero
+ * so that the host needs ONE device-to-host copy per batched step.  status has n_env+n_reserve words.
+ */
+int occ_step_flags(const uint8_t* done, const float* loss_all, const int32_t* status, int n_env, int n_reserve,
+                   int32_t* flags, void* stream);
+
+/*
+ * Auto-reset commit ("obs = self.envs[env_idx].reset()", SubProcVecEnv.py:214, from a pre-rendered candidate):
+ * for k < n, env row pairs[2k] takes over row pairs[2k+1] of every per-env state array (el, az, radius, cam,
+ * alphas, scene) with camera_position = 0, full_reward = loss, object_mass = loss + 1 (environment.py:302-324),
+ * and obs[dst] = obs_all[src].  All arrays hold n_env + n_reserve rows except campos/full_reward/object_mass/obs
+ * (n_env rows).
+ */
+int occ_reset_commit(const int32_t* pairs, int n, float* el, float* az, float* radius, float* campos, float* cam,
+                     float* alphas, float* full_reward, float* object_mass, int32_t* scene_mesh, float* scene_offset,
+                     float* obs, const float* obs_all, const float* loss_all, int img, void* stream);
+
+/*
  * Measurement hooks (bench.py only; not part of the reference surface).  While enabled, occ_render
  * brackets its dominant kernel (occ_raster_kernel) with HIP events on the launch stream.
  * occ_profile_read synchronises the recorded events (host sync!), returns the summed duration in

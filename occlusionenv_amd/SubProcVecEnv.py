@@ -178,19 +178,19 @@ class SimpleVecEnv(VecEnv):
             self._warm_reserve()
         if R:
             obs, rewards, dones, full_state, loss, out = eng.step(actions, with_reserve=True)
-            rs_ok = out["loss_all"][N:] > 0.1
+            flags = eng.step_flags(out["done_u8"], out["loss_all"])
         else:
             obs, rewards, dones, full_state, loss = eng.step(actions)
-            rs_ok = torch.zeros(0, dtype=torch.bool, device=eng.device)
+            flags = eng.step_flags(dones.to(torch.uint8), None)
         infos = _LazyInfos(eng, full_state, loss)
         # ONE host sync per batched step: which envs finished, which reserve scenes pass the reset test
         # (loss > 0.1, environment.py:327), kernel status words
-        flags = torch.cat([dones.any()[None], eng.status.any()[None], rs_ok]).cpu()
-        if bool(flags[1]):
+        fl = flags.cpu().numpy()
+        if fl[-1]:
             eng.check_status()
+        refill = []
         if R:
-            ok = flags[2:].tolist()
-            redraw = []
+            ok = fl[N:N + R]
             for r in range(R):  # every slot was rendered by this launch with its current scene
                 if self._rs_ready[r]:
                     continue
@@ -198,11 +198,10 @@ class SimpleVecEnv(VecEnv):
                 if ok[r] or self._rs_tries[r] >= 10:  # accept, or keep the 10th try regardless (environment.py:327)
                     self._rs_ready[r] = True
                 else:
-                    redraw.append(r)
-            self._refill_reserve(redraw)
-        if bool(flags[0]):
+                    refill.append(r)
+        fin_l = np.nonzero(fl[:N])[0].tolist()
+        if fin_l:
             # save final observation where user can get it, then reset (SubProcVecEnv.py:211-214)
-            fin_l = torch.nonzero(dones).reshape(-1).tolist()
             term = obs[fin_l].clone()
             for j, i in enumerate(fin_l):
                 infos.set(i, "terminal_observation", term[j:j + 1])
@@ -214,14 +213,16 @@ class SimpleVecEnv(VecEnv):
                 else:
                     left.append(i)
             if take:
+                # NB out["obs_all"][:N] IS obs: the commit kernel writes the reset observation in place
                 eng.commit_from_reserve([i for i, _ in take], [r for _, r in take], out)
                 for i, r in take:
                     self.envs[i]._scene = self._rs_scene[r]
                     self.envs[i].image = out["full_state_all"][N + r:N + r + 1]
                     self._rs_tries[r] = 0
-                self._refill_reserve([r for _, r in take])
+                    refill.append(r)
             if left:  # reserve exhausted: synchronous batched reset for the rest
                 obs[left] = self._reset_envs(left, torch.zeros(len(left)))[:, 0]
+        self._refill_reserve(refill)
         return obs, rewards, dones, infos
 
     def seed(self, seed=None):

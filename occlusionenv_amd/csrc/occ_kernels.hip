@@ -1393,6 +1393,61 @@ __global__ __launch_bounds__(64) void occ_finish_kernel(const float* __restrict_
     }
 }
 
+// One small int32 buffer per step for the host: [0..n) done, [n..n+r) reserve scene passes the reset test
+// (loss > 0.1, environment.py:327), [n+r] any kernel status bit set -> ONE device-to-host copy per step.
+__global__ __launch_bounds__(256) void occ_flags_kernel(const uint8_t* __restrict__ done, const float* __restrict__ loss_all,
+                                                        const int* __restrict__ status, int n, int r,
+                                                        int* __restrict__ flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) flags[n + r] = 0;
+    if (i < n) flags[i] = done[i];
+    else if (i < n + r) flags[i] = loss_all[i] > kDoneThreshold ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void occ_status_any_kernel(const int* __restrict__ status, int nt, int* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nt && status[i] != 0) atomicOr(out, 1);
+}
+
+// Auto-reset commit: env dst[k] takes over reserve row src[k] (all per-env state + the freshly rendered
+// observation) in one launch.  block = one (k, array) pair chunk.
+struct CommitArgs {
+    const int* pairs;  // (n,2): dst env row, src row
+    int n;
+    float* el; float* az; float* radius; float* campos; float* cam; float* alphas; float* full_reward; float* object_mass;
+    int* scene_mesh; float* scene_offset; float* obs; const float* obs_all; const float* loss_all;
+    int img;
+};
+__global__ __launch_bounds__(256) void occ_commit_kernel(CommitArgs a) {
+    const int k = blockIdx.x;
+    const int dst = a.pairs[2 * k], src = a.pairs[2 * k + 1];
+    const int tid = threadIdx.x;
+    const size_t S2 = (size_t)a.img * a.img;
+    if (blockIdx.y == 0) {
+        if (tid == 0) {
+            a.el[dst] = a.el[src];
+            a.az[dst] = a.az[src];
+            a.radius[dst] = a.radius[src];
+            const float l = a.loss_all[src];
+            a.full_reward[dst] = l;
+            a.object_mass[dst] = l + 1.0f;
+        }
+        if (tid < 3) {
+            a.campos[dst * 3 + tid] = 0.f;
+            a.scene_mesh[dst * 3 + tid] = a.scene_mesh[src * 3 + tid];
+        }
+        if (tid < 9) a.scene_offset[dst * 9 + tid] = a.scene_offset[src * 9 + tid];
+        if (tid < OCC_CAM_STRIDE) a.cam[(size_t)dst * OCC_CAM_STRIDE + tid] = a.cam[(size_t)src * OCC_CAM_STRIDE + tid];
+    } else if (blockIdx.y == 1) {
+        const float4* s4 = reinterpret_cast<const float4*>(a.obs_all + (size_t)src * 4 * S2);
+        float4* d4 = reinterpret_cast<float4*>(a.obs + (size_t)dst * 4 * S2);
+        for (size_t i = tid; i < S2; i += 256) d4[i] = s4[i];
+    } else {
+        const float* s1 = a.alphas + (size_t)src * 3 * S2;
+        float* d1 = a.alphas + (size_t)dst * 3 * S2;
+        for (size_t i = tid; i < 3 * S2; i += 256) d1[i] = s1[i];
+    }
+}
+
 }  // namespace occ
 
 // ------------------------------------------------------------------------------------------
@@ -1572,6 +1627,31 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
         if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
     }
     return OCC_OK;
+}
+
+extern "C" int occ_step_flags(const uint8_t* done, const float* loss_all, const int32_t* status, int n_env, int n_reserve,
+                              int32_t* flags, void* stream) {
+    if (!done || !status || !flags || n_env <= 0 || n_reserve < 0 || (n_reserve > 0 && !loss_all)) return OCC_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int tot = n_env + n_reserve;
+    hipLaunchKernelGGL(occ_flags_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, done, loss_all, status, n_env, n_reserve,
+                       flags);
+    hipLaunchKernelGGL(occ_status_any_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, status, tot, flags + tot);
+    return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
+}
+
+extern "C" int occ_reset_commit(const int32_t* pairs, int n, float* el, float* az, float* radius, float* campos, float* cam,
+                                float* alphas, float* full_reward, float* object_mass, int32_t* scene_mesh,
+                                float* scene_offset, float* obs, const float* obs_all, const float* loss_all, int img,
+                                void* stream) {
+    if (n == 0) return OCC_OK;
+    if (!pairs || n < 0 || !el || !az || !radius || !campos || !cam || !alphas || !full_reward || !object_mass ||
+        !scene_mesh || !scene_offset || !obs || !obs_all || !loss_all || img <= 0)
+        return OCC_ERR_ARG;
+    CommitArgs a{pairs, n, el, az, radius, campos, cam, alphas, full_reward, object_mass, scene_mesh, scene_offset,
+                 obs, obs_all, loss_all, img};
+    hipLaunchKernelGGL(occ_commit_kernel, dim3(n, 3), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
 }
 
 extern "C" int occ_step_finish(const float* loss, const float* grad_elaz, const float* cam, float* full_reward,

@@ -14,6 +14,7 @@ import ctypes as C
 import os
 from typing import Optional
 
+import numpy as np
 import torch
 
 from . import _native as nat
@@ -66,6 +67,8 @@ class OcclusionEngine:
         # of finished envs, rendered with the reset() camera in the SAME launch sequence (no extra launch, no
         # extra host sync when an env finishes).  They are invisible through the public (N-sized) views.
         self.R = int(reserve)
+        self._rs_mesh_host = None
+        self._rs_off_host = None
         NT = self.NT = N + self.R
         # environment state (environment.py:302-306,323-324); rows N.. belong to the reserve
         self._el_all = torch.zeros(NT, **f32)
@@ -287,32 +290,42 @@ class OcclusionEngine:
 
     def set_reserve_scenes(self, slots, mesh_ids, offsets) -> None:
         """Assign candidate scenes to reserve slots (rendered with radius 4, az = el = 0: reset()'s defaults,
-        which is what SimpleVecEnv's auto-reset uses, SubProcVecEnv.py:214)."""
+        which is what SimpleVecEnv's auto-reset uses, SubProcVecEnv.py:214).  The reserve block is mirrored on the
+        host and uploaded whole (two small contiguous copies, no scatter kernels)."""
         if not len(slots):
             return
-        idx = torch.as_tensor(slots, dtype=torch.long, device=self.device).reshape(-1) + self.N
-        m = torch.as_tensor(mesh_ids, dtype=torch.int32).reshape(-1, 3)
+        m = np.asarray(mesh_ids, dtype=np.int32).reshape(-1, 3)
         if int(m.min()) < 0 or int(m.max()) >= len(self.pool):
             raise ValueError("mesh id outside the pool")
-        self._mesh_all[idx] = m.to(self.device)
-        self._off_all[idx] = torch.as_tensor(offsets, dtype=torch.float32).reshape(-1, 3, 3).to(self.device)
+        if self._rs_mesh_host is None:
+            self._rs_mesh_host = torch.zeros(self.R, 3, dtype=torch.int32).pin_memory()
+            self._rs_off_host = torch.zeros(self.R, 3, 3, dtype=torch.float32).pin_memory()
+        sl = np.asarray(slots, dtype=np.int64)
+        self._rs_mesh_host.numpy()[sl] = m
+        self._rs_off_host.numpy()[sl] = np.asarray(offsets, dtype=np.float32).reshape(-1, 3, 3)
+        self._mesh_all[self.N:].copy_(self._rs_mesh_host, non_blocking=True)
+        self._off_all[self.N:].copy_(self._rs_off_host, non_blocking=True)
+
+    def step_flags(self, done_u8, loss_all) -> torch.Tensor:
+        """(N + R + 1) int32 on the device: done | reserve scene accepted | any status bit (one D2H copy later)."""
+        flags = torch.empty(self.NT + 1, dtype=torch.int32, device=self.device)
+        nat.check(self.lib.occ_step_flags(_p(done_u8), _p(loss_all), _p(self.status), self.N, self.R if loss_all is not None else 0,
+                                          _p(flags), self._stream()), "occ_step_flags")
+        return flags
 
     def commit_from_reserve(self, env_ids, slots, out) -> None:
-        """Install reserve slots (rendered by the last step()) as the fresh reset() state of ``env_ids``."""
-        e = torch.as_tensor(env_ids, dtype=torch.long, device=self.device).reshape(-1)
-        r = torch.as_tensor(slots, dtype=torch.long, device=self.device).reshape(-1) + self.N
-        self._mesh_all[e] = self._mesh_all[r]
-        self._off_all[e] = self._off_all[r]
-        self._rad_all[e] = self._rad_all[r]
-        self._az_all[e] = self._az_all[r]
-        self._el_all[e] = self._el_all[r]
-        self.camera_position[e] = 0.0
-        self._cam_all[e] = self._cam_all[r]
-        self._alphas_all[e] = self._alphas_all[r]
-        loss = out["loss_all"][r]
-        self.full_reward[e] = loss
-        self.object_mass[e] = loss + 1.0
-        out["obs"][e] = out["obs_all"][r]
+        """Install reserve slots (rendered by the last step()) as the fresh reset() state of ``env_ids``: one
+        small H2D copy of the (dst, src) row pairs + one kernel (occ_reset_commit)."""
+        n = len(env_ids)
+        if not n:
+            return
+        pairs = torch.tensor([[e, self.N + r] for e, r in zip(env_ids, slots)], dtype=torch.int32).to(self.device, non_blocking=True)
+        nat.check(self.lib.occ_reset_commit(_p(pairs), n, _p(self._el_all), _p(self._az_all), _p(self._rad_all),
+                                            _p(self.camera_position), _p(self._cam_all), _p(self._alphas_all),
+                                            _p(self.full_reward), _p(self.object_mass), _p(self._mesh_all),
+                                            _p(self._off_all), _p(out["obs_all"]), _p(out["obs_all"]), _p(out["loss_all"]),
+                                            self.S, self._stream()), "occ_reset_commit")
+        out["_pairs"] = pairs
 
     def step(self, actions: torch.Tensor, env_ids=None, with_reserve: bool = False):
         """Batched step(): returns (obs (n,4,S,S), reward (n,) [autograd-attached], done (n,) bool, full_state, loss).
@@ -343,6 +356,7 @@ class OcclusionEngine:
         if need_grad:
             reward = _RewardGrad.apply(actions, reward, grad_action)
         res = (out["obs"], reward, done.bool(), out["full_state"], out["loss"])
+        out["done_u8"] = done
         return res + (out,) if with_reserve else res
 
     def _render_with_reserve(self, actions, flags):
