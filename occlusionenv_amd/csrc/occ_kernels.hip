@@ -298,40 +298,26 @@ template <bool GRAD>
 __device__ __forceinline__ void write_record(float* __restrict__ r, uint4* __restrict__ bb, const Tri& t,
                                              int face_id, int flags) {
     const float x0 = t.v[0].x, y0 = t.v[0].y, x1 = t.v[1].x, y1 = t.v[1].y, x2 = t.v[2].x, y2 = t.v[2].y;
-    float o[OCC_REC_STRIDE];
-#pragma unroll
-    for (int i = 0; i < OCC_REC_STRIDE; ++i) o[i] = 0.f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        o[3 * k] = t.v[k].x;
-        o[3 * k + 1] = t.v[k].y;
-        o[3 * k + 2] = t.v[k].z;
-        if (GRAD) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[R_TAN + 4 * k + j] = t.v[k].t[j];
-        }
-    }
-    o[R_ID] = __int_as_float(face_id);
-    o[R_FLAGS] = __int_as_float(flags);
     // [P3D] BarycentricCoordsForward: area = EdgeFunction(v2; v0, v1) + kEpsilon
     const float area = (x2 - x0) * (y1 - y0) - (y2 - y0) * (x1 - x0) + kEpsilon;
-    o[R_INV_AREA] = 1.0f / area;
-    o[R_BX0] = fmin3(x0, x1, x2) - kSqrtBlur;
-    o[R_BX1] = fmax3(x0, x1, x2) + kSqrtBlur;
-    o[R_BY0] = fmin3(y0, y1, y2) - kSqrtBlur;
-    o[R_BY1] = fmax3(y0, y1, y2) + kSqrtBlur;
     const float l01 = (x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0);
     const float l02 = (x2 - x0) * (x2 - x0) + (y2 - y0) * (y2 - y0);
     const float l12 = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
-    o[R_IL01] = l01 <= kEpsilon ? -1.0f : 1.0f / l01;
-    o[R_IL02] = l02 <= kEpsilon ? -1.0f : 1.0f / l02;
-    o[R_IL12] = l12 <= kEpsilon ? -1.0f : 1.0f / l12;
-    o[R_ILE01] = 1.0f / (l01 + kEpsilon);
-    o[R_ILE02] = 1.0f / (l02 + kEpsilon);
-    o[R_ILE12] = 1.0f / (l12 + kEpsilon);
     float4* r4 = reinterpret_cast<float4*>(r);
-#pragma unroll
-    for (int i = 0; i < OCC_REC_STRIDE / 4; ++i) r4[i] = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+    // slot map: occ_constants.h (R_X0 .. R_TAN)
+    r4[0] = make_float4(x0, y0, t.v[0].z, x1);
+    r4[1] = make_float4(y1, t.v[1].z, x2, y2);
+    r4[2] = make_float4(t.v[2].z, __int_as_float(face_id), __int_as_float(flags), 1.0f / area);
+    r4[3] = make_float4(fmin3(x0, x1, x2) - kSqrtBlur, fmax3(x0, x1, x2) + kSqrtBlur, fmin3(y0, y1, y2) - kSqrtBlur,
+                        fmax3(y0, y1, y2) + kSqrtBlur);
+    r4[4] = make_float4(l01 <= kEpsilon ? -1.0f : 1.0f / l01, l02 <= kEpsilon ? -1.0f : 1.0f / l02,
+                        l12 <= kEpsilon ? -1.0f : 1.0f / l12, 1.0f / (l01 + kEpsilon));
+    r4[5] = make_float4(1.0f / (l02 + kEpsilon), 1.0f / (l12 + kEpsilon), 0.f, 0.f);
+    if (GRAD) {
+        r4[6] = make_float4(t.v[0].t[0], t.v[0].t[1], t.v[0].t[2], t.v[0].t[3]);
+        r4[7] = make_float4(t.v[1].t[0], t.v[1].t[1], t.v[1].t[2], t.v[1].t[3]);
+        r4[8] = make_float4(t.v[2].t[0], t.v[2].t[1], t.v[2].t[2], t.v[2].t[3]);
+    }
     *bb = t.bbox;
 }
 
@@ -400,6 +386,71 @@ __global__ __launch_bounds__(256) void occ_sort_kernel(OccScene sc, OccWorkspace
     chunk_boxes(scan, reinterpret_cast<uint4*>(ws.rec_cbox) + (size_t)eo * ((sc.rec_cap + 63) >> 6), nr, wave, lane);
 }
 
+struct CamRT {
+    float R[9], T[3], dRe[9], dTe[3], dRa[9], dTa[3];
+};
+
+template <bool GRAD>
+__device__ __forceinline__ void view_vertex(const OccScene& sc, const CamRT& c, int vo, int fo, int f, int k, float ox,
+                                            float oy, float oz, VVert& q) {
+    const int vi = sc.pool_faces[(size_t)(fo + f) * 3 + k];
+    const float* pv = sc.pool_verts + (size_t)(vo + vi) * 3;
+    // environment.py:148,171: verts + offset in f32
+    const float wx = pv[0] + ox, wy = pv[1] + oy, wz = pv[2] + oz;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        q.v[j] = wx * c.R[j] + wy * c.R[3 + j] + wz * c.R[6 + j] + c.T[j];
+        if (GRAD) {
+            q.de[j] = wx * c.dRe[j] + wy * c.dRe[3 + j] + wz * c.dRe[6 + j] + c.dTe[j];
+            q.da[j] = wx * c.dRa[j] + wy * c.dRa[3 + j] + wz * c.dRa[6 + j] + c.dTa[j];
+        }
+    }
+}
+
+// Faces that straddle z = kZClip ([P3D] clip_faces cases 3 and 4).  Rare (the camera must be within
+// ~0.5 of the geometry), so this lives out of line: it re-derives everything from the face index, both when the
+// face is counted and when its records are written, and keeps its dynamically indexed arrays off the hot path.
+template <bool GRAD>
+__device__ __attribute__((noinline)) int clip_face_slow(const OccScene& sc, const CamRT& c, int vo, int fo, int f, float ox,
+                                                        float oy, float oz, Tri* out, int* flags) {
+    VVert q[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) view_vertex<GRAD>(sc, c, vo, fo, f, k, ox, oy, oz, q[k]);
+    const bool b0 = q[0].v[2] < kZClip, b1 = q[1].v[2] < kZClip, b2 = q[2].v[2] < kZClip;
+    const int nb = (int)b0 + (int)b1 + (int)b2;
+    flags[0] = flags[1] = 0;
+    if (nb == 2) {
+        // case 3: p1 = the vertex in front; new triangle (p4, p5, p1)
+        const int i1 = !b0 ? 0 : (!b1 ? 1 : 2);
+        const int i2 = (i1 + 1) % 3, i3 = (i1 + 2) % 3;
+        out[0].v[0] = cut_edge<GRAD>(q[i1], q[i2]);
+        out[0].v[1] = cut_edge<GRAD>(q[i1], q[i3]);
+        out[0].v[2] = project<GRAD>(q[i1]);
+        return finish_tri(out[0], sc.img) ? 1 : 0;
+    }
+    if (nb == 1) {
+        // case 4: p1 = the vertex behind; quad -> (p4, p2, p5), (p5, p2, p3)
+        const int i1 = b0 ? 0 : (b1 ? 1 : 2);
+        const int i2 = (i1 + 1) % 3, i3 = (i1 + 2) % 3;
+        const PVert p4 = cut_edge<GRAD>(q[i1], q[i2]);
+        const PVert p5 = cut_edge<GRAD>(q[i1], q[i3]);
+        const PVert p2 = project<GRAD>(q[i2]);
+        const PVert p3 = project<GRAD>(q[i3]);
+        Tri ta, tb;
+        ta.v[0] = p4; ta.v[1] = p2; ta.v[2] = p5;
+        tb.v[0] = p5; tb.v[1] = p2; tb.v[2] = p3;
+        const bool oka = finish_tri(ta, sc.img), okb = finish_tri(tb, sc.img);
+        if (oka && okb) {
+            out[0] = ta; out[1] = tb;
+            flags[0] = FLAG_PAIR_FIRST; flags[1] = FLAG_PAIR_SECOND;
+            return 2;
+        }
+        if (oka) { out[0] = ta; return 1; }
+        if (okb) { out[0] = tb; return 1; }
+    }
+    return 0;  // nb == 3: the whole face is behind the clip plane
+}
+
 template <bool GRAD>
 __global__ __launch_bounds__(256) void occ_setup_kernel(OccScene sc, const float* __restrict__ cam, OccWorkspace ws) {
     __shared__ int s_wcnt[4];
@@ -413,18 +464,18 @@ __global__ __launch_bounds__(256) void occ_setup_kernel(OccScene sc, const float
     const int nF = sc.mesh_face_off[mesh + 1] - fo;
     const float ox = sc.scene_offset[eo * 3], oy = sc.scene_offset[eo * 3 + 1], oz = sc.scene_offset[eo * 3 + 2];
     const float* __restrict__ c = cam + (size_t)env * OCC_CAM_STRIDE;
-    float R[9], T[3], dRe[9], dTe[3], dRa[9], dTa[3];
+    CamRT C;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        R[i] = c[C_R + i];
-        dRe[i] = GRAD ? c[C_DR_EL + i] : 0.f;
-        dRa[i] = GRAD ? c[C_DR_AZ + i] : 0.f;
+        C.R[i] = c[C_R + i];
+        C.dRe[i] = GRAD ? c[C_DR_EL + i] : 0.f;
+        C.dRa[i] = GRAD ? c[C_DR_AZ + i] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        T[i] = c[C_T + i];
-        dTe[i] = GRAD ? c[C_DT_EL + i] : 0.f;
-        dTa[i] = GRAD ? c[C_DT_AZ + i] : 0.f;
+        C.T[i] = c[C_T + i];
+        C.dTe[i] = GRAD ? c[C_DT_EL + i] : 0.f;
+        C.dTa[i] = GRAD ? c[C_DT_AZ + i] : 0.f;
     }
     if (tid == 0) {
         s_rect[0] = 1 << 20;
@@ -440,60 +491,26 @@ __global__ __launch_bounds__(256) void occ_setup_kernel(OccScene sc, const float
     for (int base = 0; base < nF; base += 256) {
         const int f = base + tid;
         int cnt = 0;
-        Tri tri[2];
-        int flags0 = 0, flags1 = 0;
+        bool slow = false;
+        Tri tri;  // fast path: the unclipped face, positions only until it is known to survive
         if (f < nF) {
-            VVert q[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int vi = sc.pool_faces[(size_t)(fo + f) * 3 + k];
-                const float* pv = sc.pool_verts + (size_t)(vo + vi) * 3;
-                // environment.py:148,171: verts + offset in f32
-                const float wx = pv[0] + ox, wy = pv[1] + oy, wz = pv[2] + oz;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    q[k].v[j] = wx * R[j] + wy * R[3 + j] + wz * R[6 + j] + T[j];
-                    if (GRAD) {
-                        q[k].de[j] = wx * dRe[j] + wy * dRe[3 + j] + wz * dRe[6 + j] + dTe[j];
-                        q[k].da[j] = wx * dRa[j] + wy * dRa[3 + j] + wz * dRa[6 + j] + dTa[j];
-                    }
-                }
+            VVert q0, q1, q2;
+            view_vertex<false>(sc, C, vo, fo, f, 0, ox, oy, oz, q0);
+            view_vertex<false>(sc, C, vo, fo, f, 1, ox, oy, oz, q1);
+            view_vertex<false>(sc, C, vo, fo, f, 2, ox, oy, oz, q2);
+            slow = (q0.v[2] < kZClip) || (q1.v[2] < kZClip) || (q2.v[2] < kZClip);
+            if (!slow) {
+                tri.v[0] = project<false>(q0);
+                tri.v[1] = project<false>(q1);
+                tri.v[2] = project<false>(q2);
+                cnt = finish_tri(tri, sc.img) ? 1 : 0;
             }
-            const bool b0 = q[0].v[2] < kZClip, b1 = q[1].v[2] < kZClip, b2 = q[2].v[2] < kZClip;
-            const int nb = (int)b0 + (int)b1 + (int)b2;
-            if (nb == 0) {
-                tri[0].v[0] = project<GRAD>(q[0]);
-                tri[0].v[1] = project<GRAD>(q[1]);
-                tri[0].v[2] = project<GRAD>(q[2]);
-                cnt = finish_tri(tri[0], sc.img) ? 1 : 0;
-            } else if (nb == 2) {
-                // case 3: p1 = the vertex in front; new triangle (p4, p5, p1)
-                const int i1 = !b0 ? 0 : (!b1 ? 1 : 2);
-                const int i2 = (i1 + 1) % 3, i3 = (i1 + 2) % 3;
-                tri[0].v[0] = cut_edge<GRAD>(q[i1], q[i2]);
-                tri[0].v[1] = cut_edge<GRAD>(q[i1], q[i3]);
-                tri[0].v[2] = project<GRAD>(q[i1]);
-                cnt = finish_tri(tri[0], sc.img) ? 1 : 0;
-            } else if (nb == 1) {
-                // case 4: p1 = the vertex behind; quad -> (p4, p2, p5), (p5, p2, p3)
-                const int i1 = b0 ? 0 : (b1 ? 1 : 2);
-                const int i2 = (i1 + 1) % 3, i3 = (i1 + 2) % 3;
-                const PVert p4 = cut_edge<GRAD>(q[i1], q[i2]);
-                const PVert p5 = cut_edge<GRAD>(q[i1], q[i3]);
-                const PVert p2 = project<GRAD>(q[i2]);
-                const PVert p3 = project<GRAD>(q[i3]);
-                Tri ta, tb;
-                ta.v[0] = p4; ta.v[1] = p2; ta.v[2] = p5;
-                tb.v[0] = p5; tb.v[1] = p2; tb.v[2] = p3;
-                const bool oka = finish_tri(ta, sc.img), okb = finish_tri(tb, sc.img);
-                if (oka && okb) {
-                    tri[0] = ta; tri[1] = tb; cnt = 2;
-                    flags0 = FLAG_PAIR_FIRST; flags1 = FLAG_PAIR_SECOND;
-                } else if (oka) {
-                    tri[0] = ta; cnt = 1;
-                } else if (okb) {
-                    tri[0] = tb; cnt = 1;
-                }
+        }
+        if (__ballot(slow)) {
+            if (slow) {
+                Tri tmp[2];
+                int fl[2];
+                cnt = clip_face_slow<GRAD>(sc, C, vo, fo, f, ox, oy, oz, tmp, fl);
             }
         }
         // ordered compaction: exclusive prefix of cnt in {0,1,2} over the block
@@ -512,12 +529,31 @@ __global__ __launch_bounds__(256) void occ_setup_kernel(OccScene sc, const float
         const int pos = total + woff + pre;
         if (cnt >= 1) {
             if (pos + cnt <= sc.rec_cap) {
-                write_record<GRAD>(rec + (size_t)pos * OCC_REC_STRIDE, bbs + pos, tri[0], f, flags0);
-                if (cnt == 2) write_record<GRAD>(rec + (size_t)(pos + 1) * OCC_REC_STRIDE, bbs + pos + 1, tri[1], f, flags1);
-                int x0 = tri[0].tx0, y0 = tri[0].ty0, x1 = tri[0].tx1, y1 = tri[0].ty1;
-                if (cnt == 2) {
-                    x0 = min(x0, tri[1].tx0); y0 = min(y0, tri[1].ty0);
-                    x1 = max(x1, tri[1].tx1); y1 = max(y1, tri[1].ty1);
+                int x0, y0, x1, y1;
+                if (!slow) {
+                    if (GRAD) {
+                        // tangents only for the faces that survived culling
+                        VVert q;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            view_vertex<true>(sc, C, vo, fo, f, k, ox, oy, oz, q);
+                            const PVert pk = project<true>(q);
+                            tri.v[k].t[0] = pk.t[0]; tri.v[k].t[1] = pk.t[1]; tri.v[k].t[2] = pk.t[2]; tri.v[k].t[3] = pk.t[3];
+                        }
+                    }
+                    write_record<GRAD>(rec + (size_t)pos * OCC_REC_STRIDE, bbs + pos, tri, f, 0);
+                    x0 = tri.tx0; y0 = tri.ty0; x1 = tri.tx1; y1 = tri.ty1;
+                } else {
+                    Tri tmp[2];
+                    int fl[2];
+                    clip_face_slow<GRAD>(sc, C, vo, fo, f, ox, oy, oz, tmp, fl);
+                    write_record<GRAD>(rec + (size_t)pos * OCC_REC_STRIDE, bbs + pos, tmp[0], f, fl[0]);
+                    x0 = tmp[0].tx0; y0 = tmp[0].ty0; x1 = tmp[0].tx1; y1 = tmp[0].ty1;
+                    if (cnt == 2) {
+                        write_record<GRAD>(rec + (size_t)(pos + 1) * OCC_REC_STRIDE, bbs + pos + 1, tmp[1], f, fl[1]);
+                        x0 = min(x0, tmp[1].tx0); y0 = min(y0, tmp[1].ty0);
+                        x1 = max(x1, tmp[1].tx1); y1 = max(y1, tmp[1].ty1);
+                    }
                 }
                 atomicMin(&s_rect[0], x0);
                 atomicMin(&s_rect[1], y0);
