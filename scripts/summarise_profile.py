@@ -30,7 +30,7 @@ def counters(sub):
     return agg
 
 
-KEY = "occ_tile_kernel<true, true, true>"
+KEY = "occ_raster_kernel<true, true, true>"
 summary = {"kernel": KEY, "note": "per-launch means over the full-batch step launches; FETCH_SIZE/WRITE_SIZE in KiB as "
            "rocprofv3 reports them; hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 x2 read "
            "correction of MI355X_MICROARCH.md (HBM section), calibrated there for wide coalesced streams only"}
