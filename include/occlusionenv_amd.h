@@ -87,11 +87,11 @@ typedef struct OccWorkspace {
     uint32_t* scan;     /* (n_env,3,rec_cap,4) the same rows sorted front to back, .w = record index (the raster scan order) */
     int32_t* nrec;      /* (n_env,3) */
     int32_t* objrect;   /* (n_env,3,4) block rect bx0,by0,bx1,by1 (inclusive, OCC_BLOCK-pixel units) */
-    uint32_t* queue;    /* (16) work-queue head (zeroed by occ_render) */
+    uint32_t* queue;    /* (8,16) one work-queue head per XCD group, a 64-B line each (zeroed by occ_render) */
     float* lists;       /* (n_slots,OCC_LIST_CAP,64,4) per-wave K-buffer rows: (key(z) u32, 1-p, g_el, g_az) per lane */
     float* partials;    /* (n_env,ceil(S*S/256),4) per-block loss / gradient partial sums */
     int32_t* status;    /* (n_env) OCC_STATUS_* bits, OR-ed in; caller clears */
-    int32_t* offsets;   /* (n_env*3+1) first work item of every (env, object) */
+    int32_t* offsets;   /* (8*3*ceil(n_env/8)+1) first work item of every (env, object), XCD-major order */
     uint32_t* rec_cbox; /* (n_env,3,ceil(rec_cap/64),4) union pixel bbox + nearest depth key of every 64-entry scan chunk */
     float* obj_alpha;   /* (n_env,3,S,S) per-object silhouette alpha, valid inside the object's tile rect */
     float* obj_grad;    /* (n_env,3,S,S,2) d alpha / d(el, az) */

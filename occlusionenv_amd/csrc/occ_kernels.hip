@@ -869,19 +869,32 @@ struct RasterParams {
     int ntx;  // tiles per image side
 };
 
-// One block: exclusive prefix sum of the tile counts of every (env, object) rect -> work-item offsets.
+// XCD-major order of the (env, object) pairs: env e belongs to XCD group e % 8; group g holds MQ = 3*ceil(N/8) slots.
+// All blocks of an env are then dequeued by waves of ONE XCD (when placement follows XCC_ID), so the face
+// records of an object, staged again by every block they touch, are fetched into one L2 instead of eight.
+__host__ __device__ __forceinline__ int xcd_slots(int n_env) { return 3 * ((n_env + 7) / 8); }
+__device__ __forceinline__ int perm_to_eo(int p, int mq, int n_env) {
+    const int g = p / mq, slot = p - g * mq;
+    const int e = (slot / 3) * 8 + g;
+    return e < n_env ? e * 3 + slot % 3 : -1;
+}
+
+// One block: exclusive prefix sum of the block counts of every (env, object) rect, in XCD-major order
+// -> work-item offsets (8*MQ + 1 entries).
 __global__ __launch_bounds__(1024) void occ_scan_kernel(const int* __restrict__ objrect, const int* __restrict__ nrec,
-                                                        int* __restrict__ offsets, int M) {
+                                                        int* __restrict__ offsets, int n_env) {
     __shared__ int s_part[16];
     __shared__ int s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mq = xcd_slots(n_env), M = 8 * mq;
     if (tid == 0) s_carry = 0;
     __syncthreads();
     for (int base = 0; base < M; base += 1024) {
         const int i = base + tid;
         int c = 0;
-        if (i < M && nrec[i] > 0) {
-            const int w = objrect[4 * i + 2] - objrect[4 * i] + 1, h = objrect[4 * i + 3] - objrect[4 * i + 1] + 1;
+        const int eo = i < M ? perm_to_eo(i, mq, n_env) : -1;
+        if (eo >= 0 && nrec[eo] > 0) {
+            const int w = objrect[4 * eo + 2] - objrect[4 * eo] + 1, h = objrect[4 * eo + 3] - objrect[4 * eo + 1] + 1;
             c = (w > 0 && h > 0) ? w * h : 0;
         }
         int incl = c;  // inclusive scan inside the wave
@@ -923,7 +936,6 @@ __global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
     const int g = lane >> 4, l = lane & 15;
     const int px = l & 3, py = l >> 2;
     const int S = P.sc.img;
-    const int M = P.sc.n_env * 3;
     const float fS = (float)S;
     const int cap = P.sc.rec_cap;
     const int K = P.K;
@@ -937,21 +949,34 @@ __global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
     __shared__ float4 s_stage[kStage * 9];
     __shared__ int s_hit[kStage];  // record index of every staged face
     ciptr offs = as_const(P.ws.offsets);
-    const int total_items = offs[M];
+    const int mq = xcd_slots(P.sc.n_env), MP = 8 * mq;
+    // this wave's XCD (HW_REG_XCC_ID, bits 3:0); only steers WHICH queue is drained first - any value is correct
+    const int my_xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;
+    int qround = 0;  // queues visited so far: own XCD's first, then the others (work stealing)
 
     for (;;) {
-        int item = 0;
-        if (lane == 0) item = (int)atomicAdd(P.ws.queue, 1u);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= total_items) break;
-        // (env, object) of this item: largest eo with offsets[eo] <= item
-        int lo = 0, hi = M;
+        int item = -1;
+        while (qround < 8) {
+            const int qq = (my_xcc + qround) & 7;
+            const int qbeg = offs[qq * mq], qend = offs[(qq + 1) * mq];
+            int t = qend;
+            if (lane == 0 && qbeg < qend) t = qbeg + (int)atomicAdd(P.ws.queue + qq * 16, 1u);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t < qend) {
+                item = t;
+                break;
+            }
+            qround += 1;
+        }
+        if (item < 0) break;
+        // (env, object) of this item: largest permuted index p with offsets[p] <= item
+        int lo = 0, hi = MP;
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
             if (offs[mid] <= item) lo = mid; else hi = mid;
         }
-        const int eo = lo;
-        const int local = item - offs[eo];
+        const int eo = perm_to_eo(lo, mq, P.sc.n_env);
+        const int local = item - offs[lo];
         ciptr rect = as_const(P.ws.objrect + eo * 4);
         const int rw = rect[2] - rect[0] + 1;
         const int by = rect[1] + local / rw, bx = rect[0] + local % rw;
@@ -1569,11 +1594,11 @@ extern "C" int occ_workspace_query(const OccScene* scene, int n_slots, OccWorksp
     out->rec_cbox_bytes = N * 3 * ((cap + 63) / 64) * 4 * sizeof(uint32_t);
     out->nrec_bytes = N * 3 * sizeof(int32_t);
     out->objrect_bytes = N * 3 * 4 * sizeof(int32_t);
-    out->queue_bytes = 16 * sizeof(uint32_t);
+    out->queue_bytes = 8 * 16 * sizeof(uint32_t);  // eight queue heads, one 64-B line each
     out->lists_bytes = (size_t)n_slots * OCC_LIST_CAP * 64 * 4 * sizeof(float);
     const size_t S2 = (size_t)scene->img * scene->img;
     out->partials_bytes = N * ((S2 + 255) / 256) * 4 * sizeof(float);
-    out->offsets_bytes = (N * 3 + 1) * sizeof(int32_t);
+    out->offsets_bytes = (size_t)(8 * xcd_slots(scene->n_env) + 1) * sizeof(int32_t);
     out->obj_alpha_bytes = N * 3 * S2 * sizeof(float);
     out->obj_grad_bytes = N * 3 * S2 * 2 * sizeof(float);
     out->obj_hz_bytes = N * 3 * S2 * sizeof(float);
@@ -1608,7 +1633,7 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
     if (hard && !out->obs) return OCC_ERR_ARG;
     if (soft && (faces_per_pixel <= 0 || faces_per_pixel > OCC_MAX_K)) return OCC_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(ws->queue, 0, 16 * sizeof(uint32_t), st) != hipSuccess) return OCC_ERR_LAUNCH;
+    if (hipMemsetAsync(ws->queue, 0, 8 * 16 * sizeof(uint32_t), st) != hipSuccess) return OCC_ERR_LAUNCH;
     const int N = scene->n_env;
     if (grad)
         hipLaunchKernelGGL(occ_setup_kernel<true>, dim3(N * 3), dim3(256), 0, st, *scene, cam, *ws);
@@ -1628,7 +1653,7 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
     P.cam = cam;
     P.K = faces_per_pixel;
     P.ntx = scene->img / OCC_TILE;
-    hipLaunchKernelGGL(occ_scan_kernel, dim3(1), dim3(1024), 0, st, ws->objrect, ws->nrec, ws->offsets, N * 3);
+    hipLaunchKernelGGL(occ_scan_kernel, dim3(1), dim3(1024), 0, st, ws->objrect, ws->nrec, ws->offsets, N);
     if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
     const dim3 grid(ws->n_slots), block(64);
     const bool prof = g_prof_on && g_prof_n < kProfMax;
