@@ -1201,6 +1201,15 @@ __global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
 #else
             const bool ovf = (ctot > K) || px_any(thr_on);
 #endif
+#ifdef OCC_DBG_STATS
+            {
+                const int cw = (int)wave_sum((float)count);
+                const int co = (int)wave_sum(ovf ? (float)count : 0.f);
+                OCC_STAT(4, cw);                                   // candidates stored
+                OCC_STAT(6, co);                                   // ... of which in pixels that need selection
+                OCC_STAT(7, __ballot(ovf) ? 1 : 0);                // items with at least one such pixel
+            }
+#endif
             if (__ballot(ovf)) {
                 // more than K candidates: keep the K nearest in z, SURVEY A.4
                 float pr, se, sa;

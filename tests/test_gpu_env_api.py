@@ -139,6 +139,27 @@ def test_auto_reset_from_the_speculative_reserve(ds):
     assert torch.isfinite(r2).all()
 
 
+def test_harness_gradient_ascent_and_rollout(ds):
+    """H1 counterparts: demo.py's gradient-ascent loop reduces the occlusion; a T-step batched rollout yields
+    well-formed 261-float records and finite action gradients."""
+    from occlusionenv_amd import harness, rollout
+    from environment import OcclusionEnv
+    from SubProcVecEnv import SimpleVecEnv
+
+    np.random.seed(5)
+    env = OcclusionEnv(ds, img_size=64)
+    log, action = harness.gradient_ascent(env, steps=12, lr=0.05)
+    assert len(log) >= 1 and all(np.isfinite(r) for r, _, _ in log)
+    fulls = [f for _, f, _ in log]
+    assert min(fulls) <= fulls[0] + 1e-3  # ascent on the reward does not increase the occlusion loss overall
+    N, T = 8, 6
+    venv = SimpleVecEnv([lambda: OcclusionEnv(ds, img_size=64) for _ in range(N)])
+    out = harness.collect_rollout(venv, T=T)
+    assert out["records"].shape == (T, N, rollout.RECORD_FLOATS) and out["action_grads"].shape == (T, N, 2)
+    assert torch.isfinite(out["records"]).all() and torch.isfinite(out["action_grads"]).all()
+    assert set(out["records"][..., 260].unique().tolist()) <= {0.0, 1.0}
+
+
 def test_full_size_properties(ds):
     """BASELINE config 3 size (1024 envs, 128x128, ~5k-face meshes): properties that need no oracle."""
     from tests.parity_utils import make_case
