@@ -727,33 +727,38 @@ __device__ __forceinline__ bool px_any(bool v) { return px_sum_i(v ? 1 : 0) != 0
 // (SURVEY A.4); exact-z ties at the boundary are granted to lane 0 first, then 1, 2, 3, each in face order.
 //
 // The lists live in HBM/L2 (they do not fit LDS at 11 waves/CU), so the selection touches them as little as
-// possible: a most-significant-digit radix select, 5 bits per level.  Every lane histograms its OWN key rows
-// into a private 32-bucket u16 histogram in LDS (lane stride 17 dwords = conflict-free when lanes agree); the
+// possible: a most-significant-digit radix select, kHistBits bits per level.  Every lane histograms its OWN key
+// rows into a private u16 histogram in LDS (lane stride kHistStride dwords = conflict-free when lanes agree); the
 // four histograms of a pixel are summed with two cross-lane adds while they are scanned, so the four lanes
-// take identical decisions.  The window [L, L + 32<<sh) starts at the pixel's own [kmin, kmax] key range: two
-// levels resolve 10 bits below the first differing bit - typically enough.  Key sweeps are pipelined 8 rows
+// take identical decisions.  The window [L, L + (1 << kHistBits) << sh) starts at the pixel's own [kmin, kmax] key
+// range, so a few levels resolve the bits below the first differing one.  Key sweeps are pipelined 8 rows
 // deep.  The last sweep reads the payload rows once and takes every key below the boundary bucket plus this
 // lane's share of the keys inside it.  Pixels with active == false idle.
 // COMPACT: also moves the kept entries to the front of each list (stable) and returns the new own count.
+// radix-select digit: 4 bits -> 16 u16 buckets = 8 dwords per lane (+1 pad: conflict-free when lanes agree)
+constexpr int kHistBits = 4;
+constexpr int kHistDwords = (1 << kHistBits) / 2;
+constexpr int kHistStride = kHistDwords + 1;
+
 template <bool COMPACT>
 __device__ __forceinline__ void topk_select4(float4* __restrict__ list, uint32_t* __restrict__ hist, int lane,
                                              int cnt, int K, bool active,
                                              uint32_t kmin_own, uint32_t kmax_own, float& pr, float& se, float& sa,
                                              uint32_t& Tmax, int& kept) {
     const int maxc = wave_max_i(active ? cnt : 0);
-    uint32_t* __restrict__ h = hist + lane * 17;
+    uint32_t* __restrict__ h = hist + lane * kHistStride;
     // the key is component x of the 16-byte row entry: row e of this lane sits 256 dwords further on
     const uint32_t* __restrict__ keyp = reinterpret_cast<const uint32_t*>(list) + lane * 4;
     const uint32_t kmin = px_min_u(kmin_own), kmax = px_max_u(kmax_own);
     uint32_t L = kmin;
     const uint32_t range = kmax >= kmin ? kmax - kmin : 0u;
-    int sh = range ? max(0, (32 - __builtin_clz(range)) - 5) : 0;
+    int sh = range ? max(0, (32 - __builtin_clz(range)) - kHistBits) : 0;
     int need = K;
     int m_own = 0, mstar_px = 0;
     bool done = !active;
     while (__ballot(!done)) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) h[i] = 0u;
+        for (int i = 0; i < kHistDwords; ++i) h[i] = 0u;
         for (int e0 = 0; e0 < maxc; e0 += 8) {
             uint32_t kk[8];
 #pragma unroll
@@ -767,14 +772,14 @@ __device__ __forceinline__ void topk_select4(float4* __restrict__ list, uint32_t
                 if (!done && e < cnt) {
                     const uint32_t k = kk[i];
                     const uint32_t d = (k - L) >> sh;
-                    if (k >= L && d < 32u) h[d >> 1] += 1u << (16 * (d & 1u));
+                    if (k >= L && d < (1u << kHistBits)) h[d >> 1] += 1u << (16 * (d & 1u));
                 }
             }
         }
-        int cum = 0, bstar = 31, mstar = 0, cumb = 0, mown = 0;
+        int cum = 0, bstar = (1 << kHistBits) - 1, mstar = 0, cumb = 0, mown = 0;
         bool found = false;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < kHistDwords; ++i) {
             const uint32_t wo = h[i];
             uint32_t w = wo;  // joint histogram of the pixel: the four private ones added up
             w += (uint32_t)__shfl_xor((int)w, 16, 64);
@@ -793,7 +798,7 @@ __device__ __forceinline__ void topk_select4(float4* __restrict__ list, uint32_t
             if (mstar == need || sh == 0 || !found) {
                 done = true;
             } else {
-                sh = max(0, sh - 5);
+                sh = max(0, sh - kHistBits);
             }
         }
     }
@@ -930,8 +935,11 @@ __global__ __launch_bounds__(1024) void occ_scan_kernel(const int* __restrict__ 
 // costs a 64-lane pass.  Every pixel's candidates are therefore spread over four lanes (each in face order):
 // counts, products, tangent sums and the nearest hard face are folded across the four lanes at the end of the
 // item, and the exact top-K selection works on the four lists jointly (topk_select4).
+#ifndef OCC_RASTER_WAVES_PER_SIMD
+#define OCC_RASTER_WAVES_PER_SIMD 4
+#endif
 template <bool SOFT, bool HARD, bool GRAD>
-__global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
+__global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kernel(RasterParams P) {
     const int lane = threadIdx.x;
     const int g = lane >> 4, l = lane & 15;
     const int px = l & 3, py = l >> 2;
@@ -941,7 +949,7 @@ __global__ __launch_bounds__(64) void occ_raster_kernel(RasterParams P) {
     const int K = P.K;
     // per-wave K-buffer: OCC_LIST_CAP rows of 64 lane entries (key(z), 1-p, g_el, g_az), 16 B each
     float4* __restrict__ mylist = reinterpret_cast<float4*>(P.ws.lists) + (size_t)blockIdx.x * OCC_LIST_CAP * 64;
-    __shared__ uint32_t s_hist[64 * 17];
+    __shared__ uint32_t s_hist[64 * kHistStride];
     // records of the faces that touch this block, gathered over as many 64-face chunks as fit, staged by
     // cooperative 16-B loads (one memory round trip per <= 64 staged faces)
     constexpr int kParts = GRAD ? 9 : (SOFT ? 6 : 4);  // float4 parts of a record that this variant reads

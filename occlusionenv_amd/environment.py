@@ -34,6 +34,12 @@ from .spaces import Box
 # ~20 us construction cost per draw.
 _SCENE_RNG = np.random.default_rng()
 
+
+def seed_scene_rng(seed=None) -> None:
+    """Test hook: make the category/model draws reproducible (the reference's are not)."""
+    global _SCENE_RNG
+    _SCENE_RNG = np.random.default_rng(seed)
+
 # one pool per device, shared by every env/VecEnv in the process (a ShapeNet model is uploaded once)
 _POOLS: Dict[str, MeshPool] = {}
 
