@@ -15,8 +15,8 @@
  *                                                                   -> occ_render
  *   - reward bookkeeping environment.py:382-392 and the action Jacobian :356-361
  *                                                                   -> occ_step_finish
- *   - the operator-level replacement of _C.rasterize_meshes / _C.rasterize_meshes_backward
- *     (K-buffer in PyTorch3D layout)                                -> occ_rasterize_meshes*
+ *   - SimpleVecEnv.step_wait's per-step host hand-off and auto-reset (SubProcVecEnv.py:209-218)
+ *                                                                   -> occ_step_flags, occ_reset_commit
  *
  * Conventions: plain pointers and sizes only; every pointer is DEVICE memory owned by the
  * caller (PyTorch's ROCm allocator in the Python host); calls are asynchronous on `stream`

@@ -65,3 +65,6 @@ def test_workspace_query_and_argument_checks_need_no_gpu():
     assert lib.occ_camera(0, None, None, None, None, None, None, 4, None) == 1
     assert lib.occ_render(None, None, None, None, 3, 100, None) == 1
     assert lib.occ_step_finish(None, None, None, None, None, None, None, None, 4, None) == 1
+    assert lib.occ_step_flags(None, None, None, 4, 0, None, None) == 1
+    assert lib.occ_reset_commit(None, 2, *([None] * 13), 64, None) == 1
+    assert lib.occ_reset_commit(None, 0, *([None] * 13), 64, None) == 0  # nothing to commit
