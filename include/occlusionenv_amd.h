@@ -15,6 +15,9 @@
  *                                                                   -> occ_render
  *   - reward bookkeeping environment.py:382-392 and the action Jacobian :356-361
  *                                                                   -> occ_step_finish
+ *   - the operator-level replacement of _C.rasterize_meshes / _C.rasterize_meshes_backward (K-buffer in
+ *     PyTorch3D layout, naive path)                                 -> occ_rasterize_meshes_naive,
+ *                                                                      occ_rasterize_meshes_backward_dists
  *   - SimpleVecEnv.step_wait's per-step host hand-off and auto-reset (SubProcVecEnv.py:209-218)
  *                                                                   -> occ_step_flags, occ_reset_commit
  *
@@ -149,6 +152,26 @@ int occ_render(const OccScene* scene, const float* cam, const OccWorkspace* ws,
 int occ_step_finish(const float* loss, const float* grad_elaz, const float* cam,
                     float* full_reward, const float* object_mass, float* reward, uint8_t* done,
                     float* grad_action, int n_env, void* stream);
+
+/*
+ * Operator-level drop-in for PyTorch3D's `_C.rasterize_meshes` (naive path, bin_size = 0) and the `dists` part of
+ * `_C.rasterize_meshes_backward` - the ops environment.py reaches through MeshRasterizer (:258-262, :276-280;
+ * signatures in SURVEY.md §8b).  face_verts (F,3,3) = (x_ndc, y_ndc, z_view) AFTER clip_faces; outputs in
+ * PyTorch3D's layout: pix_to_face (N,H,W,K) int64 (packed face index, -1 empty), zbuf, dists (N,H,W,K),
+ * bary (N,H,W,K,3), slots ascending in (z, face).  Built for exactness (reference arithmetic order, no FMA
+ * contraction), not speed: the fused occ_render never materialises these buffers.
+ * grad_face_verts (F,3,3) is overwritten; only x,y receive gradient (zbuf / bary gradients are zero on the
+ * OcclusionEnv path and are not computed).
+ */
+int occ_rasterize_meshes_naive(const float* face_verts, const int64_t* mesh_to_face_first_idx,
+                               const int64_t* num_faces_per_mesh, const int64_t* clipped_faces_neighbor_idx,
+                               int n_meshes, int H, int W, float blur_radius, int faces_per_pixel,
+                               int perspective_correct, int clip_barycentric_coords, int cull_backfaces,
+                               int64_t* pix_to_face, float* zbuf, float* bary, float* dists, void* stream);
+int occ_rasterize_meshes_backward_dists(const float* face_verts, const int64_t* pix_to_face, const float* grad_dists,
+                                        int64_t n_faces, int n_meshes, int H, int W, int faces_per_pixel,
+                                        int perspective_correct, int clip_barycentric_coords, float* grad_face_verts,
+                                        void* stream);
 
 /*
  * Host hand-off of SimpleVecEnv.step_wait (SubProcVecEnv.py:209-218): one int32 buffer

@@ -104,6 +104,10 @@ SYMBOLS = {
     "occ_render": (C.c_int, [C.POINTER(OccScene), C.c_void_p, C.POINTER(OccWorkspace), C.POINTER(OccRenderOut),
                              C.c_int, C.c_int, C.c_void_p]),
     "occ_step_finish": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_void_p]),
+    "occ_rasterize_meshes_naive": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                             C.c_int, C.c_int] + [C.c_void_p] * 5),
+    "occ_rasterize_meshes_backward_dists": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                      C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "occ_step_flags": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "occ_reset_commit": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 13 + [C.c_int, C.c_void_p]),
     "occ_profile_enable": (C.c_int, [C.c_int]),

@@ -1,0 +1,73 @@
+"""Operator-level drop-in for ``pytorch3d.renderer.mesh.rasterize_meshes`` as the reference reaches it through
+``MeshRasterizer`` (/root/reference/environment.py:258-262, :276-280): the naive
+(``bin_size=0``) rasteriser with K-buffer outputs in PyTorch3D's layout, differentiable w.r.t. ``face_verts``
+through ``dists``.  ``OcclusionEnv.step`` does NOT go through here (it uses the fused ``occ_render``); this is for
+callers of the rasteriser itself and for parity tests at that boundary.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _native as nat
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class _RasterizeFaceVerts(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, face_verts, first_idx, num_faces, neighbor, H, W, blur_radius, K, persp, clipb, cull):
+        lib = nat.load()
+        if not face_verts.is_cuda:
+            raise nat.NativeError("rasterize_meshes needs CUDA/ROCm tensors; there is no CPU fallback")
+        fv = face_verts.detach().contiguous().float()
+        dev = fv.device
+        N = int(first_idx.numel())
+        first_idx = first_idx.to(dev, torch.int64).contiguous()
+        num_faces = num_faces.to(dev, torch.int64).contiguous()
+        nb = None if neighbor is None else neighbor.to(dev, torch.int64).contiguous()
+        p2f = torch.empty(N, H, W, K, dtype=torch.int64, device=dev)
+        zbuf = torch.empty(N, H, W, K, dtype=torch.float32, device=dev)
+        bary = torch.empty(N, H, W, K, 3, dtype=torch.float32, device=dev)
+        dists = torch.empty(N, H, W, K, dtype=torch.float32, device=dev)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        nat.check(lib.occ_rasterize_meshes_naive(_p(fv), _p(first_idx), _p(num_faces), _p(nb), N, H, W, float(blur_radius),
+                                                 K, int(persp), int(clipb), int(cull), _p(p2f), _p(zbuf), _p(bary),
+                                                 _p(dists), st), "occ_rasterize_meshes_naive")
+        ctx.save_for_backward(fv, p2f)
+        ctx.cfg = (N, H, W, K, int(persp), int(clipb))
+        ctx.mark_non_differentiable(p2f, zbuf, bary)
+        ctx.set_materialize_grads(False)
+        return p2f, zbuf, bary, dists
+
+    @staticmethod
+    def backward(ctx, g_p2f, g_z, g_bary, g_dists):
+        fv, p2f = ctx.saved_tensors
+        N, H, W, K, persp, clipb = ctx.cfg
+        if g_dists is None:
+            return (torch.zeros_like(fv),) + (None,) * 10
+        lib = nat.load()
+        gfv = torch.empty_like(fv)
+        st = C.c_void_p(torch.cuda.current_stream(fv.device).cuda_stream)
+        nat.check(lib.occ_rasterize_meshes_backward_dists(_p(fv), _p(p2f), _p(g_dists.contiguous().float()), fv.shape[0], N, H,
+                                                          W, K, persp, clipb, _p(gfv), st),
+                  "occ_rasterize_meshes_backward_dists")
+        return (gfv,) + (None,) * 10
+
+
+def rasterize_meshes(face_verts: torch.Tensor, mesh_to_face_first_idx: torch.Tensor, num_faces_per_mesh: torch.Tensor,
+                     image_size: int = 256, blur_radius: float = 0.0, faces_per_pixel: int = 8,
+                     perspective_correct: bool = False, clip_barycentric_coords: bool = False,
+                     cull_backfaces: bool = False, clipped_faces_neighbor_idx: Optional[torch.Tensor] = None
+                     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """``(pix_to_face, zbuf, bary_coords, dists)`` like PyTorch3D's ``_C.rasterize_meshes`` with ``bin_size=0``.
+    ``face_verts`` (F,3,3) packed (x_ndc, y_ndc, z_view) of all meshes (already z-clipped, see
+    ``clipped_faces_neighbor_idx``); ``image_size`` int or (H, W)."""
+    H, W = (image_size, image_size) if isinstance(image_size, int) else image_size
+    return _RasterizeFaceVerts.apply(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx,
+                                     int(H), int(W), blur_radius, int(faces_per_pixel), perspective_correct,
+                                     clip_barycentric_coords, cull_backfaces)
