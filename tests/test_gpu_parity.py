@@ -69,3 +69,32 @@ def test_small_list_capacity_build_forces_inloop_compaction():
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("RES")][-1]
     _check(json.loads(line[3:]))
+
+
+def test_multi_step_trajectory_matches_oracle():
+    """State carried across steps (el/az accumulation, fullReward hand-over, environment.py:354-392): five steps of a
+    gradient-ascent trajectory (demo.py:80-114) driven by the oracle's gradients, same actions on both sides."""
+    from tests.parity_utils import make_case, oracle_env
+    from occlusionenv_amd.engine import OcclusionEngine
+
+    img, T, lr = 64, 5, 0.05
+    case = make_case(1, 21, "teapot")
+    eng = OcclusionEngine(case["pool"], 1, img)
+    eng.set_scene([0], case["mesh_ids"], case["offsets"])
+    eng.reset_render(None, 4.0, case["az"], 0.0)
+    env = oracle_env(case, 0, img)
+    env.reset(azimuth=float(case["az"][0]))
+    a_o = torch.zeros(2)
+    for t in range(T):
+        ag = a_o.clone().reshape(1, 2).cuda().requires_grad_(True)
+        obs, r, d, fs, loss = eng.step(ag)
+        r.sum().backward()
+        ao = a_o.clone().requires_grad_(True)
+        obs_o, r_o, d_o, info = env.step(ao)
+        r_o.backward()
+        assert abs(float(r) - float(r_o)) < TOL, (t, float(r), float(r_o))
+        assert abs(float(loss) - float(info["full_reward"])) / max(1.0, float(info["full_reward"])) < TOL
+        assert (ag.grad[0].cpu() - ao.grad).norm() / ao.grad.norm().clamp(min=1e-6) < 2e-3
+        assert abs(float(eng.elevation[0]) - float(env.elevation)) < 1e-6 and abs(float(eng.azimuth[0]) - float(env.azimuth)) < 1e-6
+        assert torch.allclose(eng.camera_position[0].cpu(), env.camera_position.detach(), atol=1e-5)
+        a_o = (a_o + lr * ao.grad).detach()
