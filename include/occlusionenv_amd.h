@@ -81,6 +81,10 @@ typedef struct OccScene {
     int32_t n_env;
     int32_t img;       /* S: image side in pixels, multiple of 8, <= 2048 */
     int32_t rec_cap;   /* record capacity per (env, object); >= faces of the largest mesh (x2 if clipping may split) */
+    /* optional per-face texture atlases (PyTorch3D TexturesAtlas, environment.py:127,152,175); NULL = all white */
+    const float* pool_atlas;        /* packed (sum over textured meshes of F*R*R*3) */
+    const int64_t* mesh_atlas_off;  /* (n_meshes) float offset of each mesh's atlas in pool_atlas, -1 = white vertices */
+    int32_t atlas_res;              /* R */
 } OccScene;
 
 /* Caller-allocated scratch; sizes from occ_workspace_query(). */

@@ -39,6 +39,9 @@ class OccScene(C.Structure):
         ("n_env", C.c_int32),
         ("img", C.c_int32),
         ("rec_cap", C.c_int32),
+        ("pool_atlas", C.c_void_p),
+        ("mesh_atlas_off", C.c_void_p),
+        ("atlas_res", C.c_int32),
     ]
 
 

@@ -33,14 +33,14 @@ constexpr float kShadeEps = 1e-6f;
 // record slot map (OCC_REC_STRIDE floats per projected face)
 constexpr int R_X0 = 0, R_Y0 = 1, R_Z0 = 2, R_X1 = 3, R_Y1 = 4, R_Z1 = 5, R_X2 = 6, R_Y2 = 7, R_Z2 = 8;
 constexpr int R_ID = 9;        // original face id in its pool mesh (int bits)
-constexpr int R_FLAGS = 10;    // int bits: 1 = first of a clipped pair, 2 = second
+constexpr int R_FLAGS = 10;    // int bits: 1 = first of a clipped pair, 2 = second, 4 = z-clipped piece
 constexpr int R_INV_AREA = 11; // 1 / (E(v2; v0, v1) + kEpsilon)
 constexpr int R_BX0 = 12, R_BX1 = 13, R_BY0 = 14, R_BY1 = 15;  // bbox +- sqrt(blur)
 constexpr int R_IL01 = 16, R_IL02 = 17, R_IL12 = 18;           // 1/|b-a|^2, or -1 when |b-a|^2 <= kEpsilon
 constexpr int R_ILE01 = 19, R_ILE02 = 20, R_ILE12 = 21;        // 1/(|b-a|^2 + kEpsilon)  (backward)
 constexpr int R_TAN = 24;      // 12 floats: per vertex (dx/del, dy/del, dx/daz, dy/daz)
 
-constexpr int FLAG_PAIR_FIRST = 1, FLAG_PAIR_SECOND = 2;
+constexpr int FLAG_PAIR_FIRST = 1, FLAG_PAIR_SECOND = 2, FLAG_CLIPPED = 4;  // CLIPPED: record is a z-clipped piece of its face
 
 // camera buffer slot map (OCC_CAM_STRIDE floats per env)
 constexpr int C_R = 0, C_T = 9, C_C = 12, C_DR_EL = 15, C_DT_EL = 24, C_DR_AZ = 27, C_DT_AZ = 36, C_J = 39,

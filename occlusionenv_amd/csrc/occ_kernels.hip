@@ -418,7 +418,7 @@ __device__ __attribute__((noinline)) int clip_face_slow(const OccScene& sc, cons
     for (int k = 0; k < 3; ++k) view_vertex<GRAD>(sc, c, vo, fo, f, k, ox, oy, oz, q[k]);
     const bool b0 = q[0].v[2] < kZClip, b1 = q[1].v[2] < kZClip, b2 = q[2].v[2] < kZClip;
     const int nb = (int)b0 + (int)b1 + (int)b2;
-    flags[0] = flags[1] = 0;
+    flags[0] = flags[1] = FLAG_CLIPPED;
     if (nb == 2) {
         // case 3: p1 = the vertex in front; new triangle (p4, p5, p1)
         const int i1 = !b0 ? 0 : (!b1 ? 1 : 2);
@@ -442,7 +442,7 @@ __device__ __attribute__((noinline)) int clip_face_slow(const OccScene& sc, cons
         const bool oka = finish_tri(ta, sc.img), okb = finish_tri(tb, sc.img);
         if (oka && okb) {
             out[0] = ta; out[1] = tb;
-            flags[0] = FLAG_PAIR_FIRST; flags[1] = FLAG_PAIR_SECOND;
+            flags[0] = FLAG_PAIR_FIRST | FLAG_CLIPPED; flags[1] = FLAG_PAIR_SECOND | FLAG_CLIPPED;
             return 2;
         }
         if (oka) { out[0] = ta; return 1; }
@@ -1389,7 +1389,7 @@ __global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bp
             float sa = fmaxf(vx * rx + vy * ry + vz * rz, 0.f) * (cosang > 0.f ? 1.f : 0.f);
             sa *= sa; sa *= sa; sa *= sa; sa *= sa; sa *= sa; sa *= sa;  // ^64
             const float spec = kSpecular * sa;
-            // texel: white TexturesVertex interpolated with the (unclipped) barycentrics
+            // texel: white TexturesVertex interpolated with the (unclipped) barycentrics, or the face's atlas
             const float fS = (float)S;
             const float xf = -1.0f + (2.0f * (float)(S - 1 - xi) + 1.0f) / fS;
             const float yf = -1.0f + (2.0f * (float)(S - 1 - yi) + 1.0f) / fS;
@@ -1401,9 +1401,39 @@ __global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bp
             const float b2 = ((xf - x0) * (y1 - y0) - (yf - y0) * (x1 - x0)) * ia;
             const float w0 = b0 * z1 * z2, w1 = z0 * b1 * z2, w2 = z0 * z1 * b2;
             const float den = fmaxf(w0 + w1 + w2, kEpsilon);
-            const float texel = w0 / den + w1 / den + w2 / den;
-            const float col = (kAmbient + diffuse) * texel + spec;
-            cr = cg = cb = col;
+            float q0 = w0 / den, q1 = w1 / den, q2 = w2 / den;
+            float tr = q0 + q1 + q2, tg = tr, tb = tr;
+            const int64_t aoff = P.sc.pool_atlas ? P.sc.mesh_atlas_off[mesh] : -1;
+            if (aoff >= 0) {
+                if (__float_as_int(r[R_FLAGS]) & FLAG_CLIPPED) {
+                    // [P3D] convert_clipped_rasterization_to_original_faces: barycentrics w.r.t. the ORIGINAL face.
+                    // Perspective-correct barycentrics are the 3-D ones: beta_i ~ d . (V_j x V_k) with d the pixel ray
+                    // and V the face's view-space vertices (valid for vertices behind the clip plane too).
+                    float V[3][3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            V[k][j] = w[k][0] * cm[C_R + j] + w[k][1] * cm[C_R + 3 + j] + w[k][2] * cm[C_R + 6 + j] + cm[C_T + j];
+                    const float dx = xf / kProjScale, dy = yf / kProjScale, dz = 1.0f;
+                    auto tri = [&](const float* a, const float* b) {
+                        return dx * (a[1] * b[2] - a[2] * b[1]) + dy * (a[2] * b[0] - a[0] * b[2]) + dz * (a[0] * b[1] - a[1] * b[0]);
+                    };
+                    const float e0 = tri(V[1], V[2]), e1 = tri(V[2], V[0]), e2 = tri(V[0], V[1]);
+                    const float es = e0 + e1 + e2;
+                    q0 = e0 / es; q1 = e1 / es; q2 = e2 / es;
+                }
+                // [P3D] TexturesAtlas.sample_textures: (w0, w1) -> texel of the R x R grid, upper triangle mirrored
+                const int Rr = P.sc.atlas_res;
+                int wx = min((int)(q0 * (float)Rr), Rr - 1), wy = min((int)(q1 * (float)Rr), Rr - 1);
+                const bool below = ((q0 + q1) * (float)Rr - ((float)wx + (float)wy)) <= 1.0f;
+                if (!below) { wx = Rr - 1 - wx; wy = Rr - 1 - wy; }
+                const float* tx = P.sc.pool_atlas + aoff + (((size_t)fid * Rr + wy) * Rr + wx) * 3;
+                tr = tx[0]; tg = tx[1]; tb = tx[2];
+            }
+            cr = (kAmbient + diffuse) * tr + spec;
+            cg = (kAmbient + diffuse) * tg + spec;
+            cb = (kAmbient + diffuse) * tb + spec;
             depth = hz;
         }
         float* __restrict__ ob = P.out.obs + (size_t)env * 4 * S * S + gp;

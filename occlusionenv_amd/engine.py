@@ -109,6 +109,9 @@ class OcclusionEngine:
         sc.scene_mesh, sc.scene_offset = scene_mesh.data_ptr(), scene_offset.data_ptr()
         sc.n_meshes, sc.n_env, sc.img = len(self.pool), n, self.S
         sc.rec_cap = self._rec_cap()
+        atlas, aoff = self.pool.atlas_tensors()
+        if atlas is not None:
+            sc.pool_atlas, sc.mesh_atlas_off, sc.atlas_res = atlas.data_ptr(), aoff.data_ptr(), self.pool.atlas_res
         return sc
 
     def _rec_cap(self) -> int:

@@ -97,7 +97,8 @@ def sample_scene(dataset, pool: MeshPool, num_objects: int = 3) -> Tuple[List[in
             key = (id(dataset), model_idx)
             if key not in pool._keys:
                 obj = dataset[model_idx]
-                pool.add(obj["verts"], obj["faces"], key=key)
+                # environment.py:126-129: TexturesAtlas when the model has textures, else white TexturesVertex
+                pool.add(obj["verts"], obj["faces"], key=key, atlas=obj.get("textures"))
             ids.append(pool._keys[key])
     x2 = float(np.random.randn())
     offsets = [[0.0, 0.0, 0.0], [x2, 0.0, distance / 2], [-x2, 0.0, float(distance)]][:num_objects]

@@ -146,12 +146,17 @@ class SyntheticShapeNet:
     (environment.py:106-135).  ``mixed=True`` draws face counts {1280, 5120, 20480} with weights
     {0.25, 0.6, 0.15}; otherwise every mesh has 5120 faces (the headline workload)."""
 
-    def __init__(self, n_models: int = 64, seed: int = 1234, mixed: bool = False, n_categories: int = 4):
+    def __init__(self, n_models: int = 64, seed: int = 1234, mixed: bool = False, n_categories: int = 4,
+                 textured: bool = False, atlas_res: int = 4):
         rng = np.random.default_rng(seed)
         self.models: List[Tuple[torch.Tensor, torch.Tensor]] = []
+        self.atlases: List[Optional[torch.Tensor]] = []
         for _ in range(n_models):
             level = int(rng.choice([1280, 5120, 20480], p=[0.25, 0.6, 0.15])) if mixed else 5120
             self.models.append(synthetic_mesh(rng, level))
+            # ShapeNetCore(load_textures=True) hands out a per-face (F, R, R, 3) atlas, R = 4 (environment.py:127)
+            self.atlases.append(torch.tensor(rng.random((level, atlas_res, atlas_res, 3)), dtype=torch.float32)
+                                if textured else None)
         n_categories = max(1, min(n_categories, n_models))
         per = n_models // n_categories
         self.synset_dict = {f"{i:08d}": f"synthetic_{i}" for i in range(n_categories)}
@@ -167,7 +172,7 @@ class SyntheticShapeNet:
         idx = int(idx)
         v, f = self.models[idx]
         cat = max(k for k, s in self.synset_start_idxs.items() if s <= idx)
-        return {"verts": v, "faces": f, "textures": None, "synset_id": cat, "label": self.synset_dict[cat],
+        return {"verts": v, "faces": f, "textures": self.atlases[idx], "synset_id": cat, "label": self.synset_dict[cat],
                 "model_id": f"model_{idx:05d}"}
 
 
@@ -180,8 +185,11 @@ class MeshPool:
         self.device = torch.device(device)
         self._verts: List[torch.Tensor] = []
         self._faces: List[torch.Tensor] = []
+        self._atlas: List[Optional[torch.Tensor]] = []  # per mesh (F,R,R,3) f32 or None (white vertices)
+        self.atlas_res = 0
         self._keys: Dict[object, int] = {}
         self._packed = None
+        self._packed_atlas = (None, None)
         self.version = 0
 
     def __len__(self):
@@ -194,9 +202,16 @@ class MeshPool:
     def num_faces(self, mesh_id: int) -> int:
         return int(self._faces[mesh_id].shape[0])
 
-    def add(self, verts: torch.Tensor, faces: torch.Tensor, key=None) -> int:
+    def add(self, verts: torch.Tensor, faces: torch.Tensor, key=None, atlas: Optional[torch.Tensor] = None) -> int:
         if key is not None and key in self._keys:
             return self._keys[key]
+        if atlas is not None:
+            atlas = torch.as_tensor(atlas, dtype=torch.float32).detach().cpu().contiguous()
+            if atlas.ndim != 4 or atlas.shape[0] != faces.shape[0] or atlas.shape[1] != atlas.shape[2] or atlas.shape[3] != 3:
+                raise ValueError("atlas must be (F, R, R, 3)")
+            if self.atlas_res not in (0, int(atlas.shape[1])):
+                raise ValueError("all texture atlases of a pool must share one resolution R")
+            self.atlas_res = int(atlas.shape[1])
         verts = torch.as_tensor(verts, dtype=torch.float32).detach().cpu().contiguous()
         faces = torch.as_tensor(faces).detach().cpu().to(torch.int32).contiguous()
         if verts.ndim != 2 or verts.shape[1] != 3 or faces.ndim != 2 or faces.shape[1] != 3:
@@ -205,6 +220,7 @@ class MeshPool:
             raise ValueError("face index out of range")
         self._verts.append(verts)
         self._faces.append(faces)
+        self._atlas.append(atlas)
         mid = len(self._verts) - 1
         if key is not None:
             self._keys[key] = mid
@@ -214,6 +230,14 @@ class MeshPool:
 
     def get(self, mesh_id: int) -> Tuple[torch.Tensor, torch.Tensor]:
         return self._verts[mesh_id], self._faces[mesh_id].long()
+
+    def get_atlas(self, mesh_id: int) -> Optional[torch.Tensor]:
+        return self._atlas[mesh_id]
+
+    def atlas_tensors(self):
+        """(packed atlas floats, per-mesh float offsets int64 with -1 = untextured) on the device, or (None, None)."""
+        self.device_tensors()
+        return self._packed_atlas
 
     def device_tensors(self):
         if self._packed is None:
@@ -229,4 +253,17 @@ class MeshPool:
                 torch.from_numpy(voff).to(self.device),
                 torch.from_numpy(foff).to(self.device),
             )
+            if any(a is not None for a in self._atlas):
+                aoff, chunks, pos = [], [], 0
+                for a in self._atlas:
+                    if a is None:
+                        aoff.append(-1)
+                    else:
+                        aoff.append(pos)
+                        chunks.append(a.reshape(-1))
+                        pos += a.numel()
+                self._packed_atlas = (torch.cat(chunks).to(self.device),
+                                      torch.tensor(aoff, dtype=torch.int64).to(self.device))
+            else:
+                self._packed_atlas = (None, None)
         return self._packed

@@ -271,7 +271,23 @@ def soft_silhouette(verts_world, faces, R, T, S):
     return sigmoid_alpha_blend(dists, p2f)
 
 
-def hard_flat_rgbd(verts_world, faces, R, T, S, verts_rgb=None):
+def sample_atlas(atlas, p2f, bary):
+    """[P3D] TexturesAtlas.sample_textures (environment.py:127,152,175 wrap ShapeNet's per-face (R,R,3) atlases):
+    the barycentric pair (w0, w1) picks a texel of the face's R x R grid; the upper triangle of each cell is
+    mirrored onto the lower one.  atlas (F,R,R,3), p2f (...,K), bary (...,K,3) -> texels (...,K,3)."""
+    Rr = atlas.shape[1]
+    mask = (p2f < 0)[..., None]
+    w01 = torch.where(mask, torch.zeros_like(bary[..., :2]), bary[..., :2])
+    w_xy = (w01 * Rr).to(torch.int64).clamp(max=Rr - 1)
+    below_diag = (w01.sum(dim=-1) * Rr - w_xy.to(bary.dtype).sum(dim=-1)) <= 1.0
+    w_x, w_y = w_xy.unbind(-1)
+    w_x = torch.where(below_diag, w_x, Rr - 1 - w_x)
+    w_y = torch.where(below_diag, w_y, Rr - 1 - w_y)
+    texels = atlas[p2f.clamp(min=0), w_y, w_x]
+    return texels * (p2f >= 0)[..., None].to(bary.dtype)
+
+
+def hard_flat_rgbd(verts_world, faces, R, T, S, verts_rgb=None, atlas=None):
     """phong_renderer(meshes_world=mesh, R=R, T=T) with HardFlatShader (environment.py:310,336,375;
     wrapper :42-51).  Returns (image (S,S,4), zbuf (S,S,1)).  White TexturesVertex unless verts_rgb."""
     dt = verts_world.dtype
@@ -292,6 +308,8 @@ def hard_flat_rgbd(verts_world, faces, R, T, S, verts_rgb=None):
     frgb = rgb[faces]  # (F,3,3)
     texels = (bary[..., None] * frgb[idx]).sum(dim=-2)  # (S,S,1,3)
     texels = torch.where(mask[..., None], torch.zeros_like(texels), texels)
+    if atlas is not None:
+        texels = sample_atlas(atlas.to(dt), p2f, bary)
     # lighting (PointLights / Materials defaults, A.7)
     L = torch.tensor(LIGHT_LOCATION, dtype=dt)
     # camera centre as get_camera_center() returns it: the translation row of inv([R|T])
@@ -324,10 +342,12 @@ class OracleEnv:
     (join_meshes_as_scene, environment.py:191).
     """
 
-    def __init__(self, objects, img_size, dtype=torch.float32):
+    def __init__(self, objects, img_size, dtype=torch.float32, atlases=None):
         self.dtype = dtype
         self.S = img_size
         self.objs = [(v.to(dtype), f.long()) for v, f in objects]
+        # per-object (F,R,R,3) texture atlases (TexturesAtlas) or None = white TexturesVertex for the whole scene
+        self.atlas = None if atlases is None else torch.cat([a.to(dtype) for a in atlases])
         vs, fs, off = [], [], 0
         for v, f in self.objs:
             vs.append(v)
@@ -337,7 +357,7 @@ class OracleEnv:
 
     def _render_all(self, R, T):
         S = self.S
-        obs_img, depth = hard_flat_rgbd(self.scene[0], self.scene[1], R[0], T[0], S)
+        obs_img, depth = hard_flat_rgbd(self.scene[0], self.scene[1], R[0], T[0], S, atlas=self.atlas)
         observation = obs_img[None].permute(0, 3, 1, 2).clone()
         observation[:, 3] = depth[None].permute(0, 3, 1, 2)[:, 0]
         imgs = [soft_silhouette(v, f, R[0], T[0], S)[None] for v, f in self.objs]
@@ -383,5 +403,5 @@ class OracleEnv:
     def render(self):
         R = look_at_rotation(self.camera_position[None, :])
         T = translation_from(R, self.camera_position[None, :])
-        img, depth = hard_flat_rgbd(self.scene[0], self.scene[1], R[0], T[0], self.S)
+        img, depth = hard_flat_rgbd(self.scene[0], self.scene[1], R[0], T[0], self.S, atlas=self.atlas)
         return img[None], depth[None]

@@ -25,9 +25,9 @@ def make_case(n_env, seed, mesh="teapot", az_range=0.6, pool=None, device="cuda"
         v, f = load_obj(os.path.join(ROOT, "tests", "golden", "teapot.obj"))
         ids = [pool.add(v, f, key="teapot")]
     else:
-        n_models, mixed = (6, False) if mesh == "synthetic" else (8, True)
-        ds = SyntheticShapeNet(n_models=n_models, seed=1234 + seed, mixed=mixed)
-        ids = [pool.add(*ds.models[i], key=("syn", mesh, seed, i)) for i in range(n_models)]
+        n_models, mixed = (8, True) if mesh == "mixed" else (6, False)
+        ds = SyntheticShapeNet(n_models=n_models, seed=1234 + seed, mixed=mixed, textured=(mesh == "textured"))
+        ids = [pool.add(*ds.models[i], key=("syn", mesh, seed, i), atlas=ds.atlases[i]) for i in range(n_models)]
     x2 = torch.randn(n_env, generator=g)
     az = (torch.rand(n_env, generator=g) * 2 - 1) * az_range
     actions = torch.randn(n_env, 2, generator=g)
@@ -42,11 +42,13 @@ def make_case(n_env, seed, mesh="teapot", az_range=0.6, pool=None, device="cuda"
 def oracle_env(case, i, img):
     from oracle import p3d_restate as O
 
-    objs = []
+    objs, atl = [], []
     for o in range(3):
-        v, f = case["pool"].get(int(case["mesh_ids"][i, o]))
+        mid = int(case["mesh_ids"][i, o])
+        v, f = case["pool"].get(mid)
         objs.append((v + case["offsets"][i, o], f))
-    return O.OracleEnv(objs, img)
+        atl.append(case["pool"].get_atlas(mid))
+    return O.OracleEnv(objs, img, atlases=atl if all(a is not None for a in atl) else None)
 
 
 def run_engine(case, img, n_env=None, faces_per_pixel=100, radius=4.0):
@@ -68,7 +70,7 @@ def run_engine(case, img, n_env=None, faces_per_pixel=100, radius=4.0):
 def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_envs=None, radius=4.0):
     case = make_case(n_env, seed, mesh, az_range)
     got = run_engine(case, img, radius=radius)
-    res = dict(obs_maxabs=0.0, alpha_maxabs=0.0, fs_maxabs=0.0, loss_rel=0.0, reward_abs=0.0, grad_rel=0.0,
+    res = dict(obs_texel_mismatch=0.0, obs_maxabs=0.0, alpha_maxabs=0.0, fs_maxabs=0.0, loss_rel=0.0, reward_abs=0.0, grad_rel=0.0,
                obs0_maxabs=0.0, loss0_rel=0.0, depth_mismatch=0.0)
     for i in (check_envs if check_envs is not None else range(n_env)):
         env = oracle_env(case, i, img)
@@ -81,7 +83,12 @@ def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_
         mism = (d_or - d_hip).abs() > 1e-3
         res["depth_mismatch"] = max(res["depth_mismatch"], float(mism.float().mean()))
         ok = ~mism
-        res["obs_maxabs"] = max(res["obs_maxabs"], float(((obs[0] - got["obs"][i]).abs() * ok).max()))
+        dobs = ((obs[0] - got["obs"][i]).abs() * ok).detach()
+        if mesh == "textured":  # count pixels whose atlas texel differs (boundary flips) instead of diffing them
+            bad = dobs[:3].max(0).values > 1e-4
+            res["obs_texel_mismatch"] = max(res["obs_texel_mismatch"], float(bad.float().mean()))
+            dobs = dobs * (~bad)
+        res["obs_maxabs"] = max(res["obs_maxabs"], float(dobs.max()))
         d0 = (obs0[0] - got["obs0"][i]).abs()
         res["obs0_maxabs"] = max(res["obs0_maxabs"], float((d0 * ((obs0[0, 3] - got["obs0"][i, 3]).abs() <= 1e-3)).max()))
         al = torch.stack([im[0, ..., 3] for im in env.alphas]).detach()

@@ -53,6 +53,20 @@ def test_z_clipped_scene():
     _check(run_parity_case(n_env=2, img=64, seed=7, mesh="teapot", az_range=0.3, radius=1.2), grad_tol=2e-3)
 
 
+def test_texture_atlas_observation():
+    """ShapeNet-style per-face (F,4,4,3) atlases (TexturesAtlas, environment.py:127): RGB of the observation."""
+    res = run_parity_case(n_env=2, img=64, seed=9, mesh="textured")
+    # a texel index can flip where a barycentric coordinate sits on a cell boundary: allow a handful of pixels
+    assert res["depth_mismatch"] < 2e-3 and res["alpha_maxabs"] < TOL and res["loss_rel"] < TOL, res
+    assert res["obs_texel_mismatch"] < 2e-3, res
+
+
+def test_texture_atlas_z_clipped():
+    """Camera inside the scene: texels of z-clipped faces use barycentrics converted back to the original face."""
+    res = run_parity_case(n_env=2, img=64, seed=10, mesh="textured", radius=1.0)
+    assert res["depth_mismatch"] < 5e-3 and res["obs_texel_mismatch"] < 5e-3 and res["obs_maxabs"] < TOL, res
+
+
 def test_img_256():
     _check(run_parity_case(n_env=1, img=256, seed=8, mesh="teapot"))
 
