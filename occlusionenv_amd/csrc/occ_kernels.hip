@@ -295,8 +295,8 @@ __device__ __forceinline__ bool finish_tri(Tri& t, int S) {
 }
 
 template <bool GRAD>
-__device__ __forceinline__ void write_record(float* __restrict__ r, uint4* __restrict__ bb, const Tri& t,
-                                             int face_id, int flags) {
+__device__ __forceinline__ void write_record(float* __restrict__ r, uint4* __restrict__ bb, uint4* __restrict__ scan_row,
+                                             int pos, const Tri& t, int face_id, int flags) {
     const float x0 = t.v[0].x, y0 = t.v[0].y, x1 = t.v[1].x, y1 = t.v[1].y, x2 = t.v[2].x, y2 = t.v[2].y;
     // [P3D] BarycentricCoordsForward: area = EdgeFunction(v2; v0, v1) + kEpsilon
     const float area = (x2 - x0) * (y1 - y0) - (y2 - y0) * (x1 - x0) + kEpsilon;
@@ -319,6 +319,8 @@ __device__ __forceinline__ void write_record(float* __restrict__ r, uint4* __res
         r4[8] = make_float4(t.v[2].t[0], t.v[2].t[1], t.v[2].t[2], t.v[2].t[3]);
     }
     *bb = t.bbox;
+    // scan row in face order (occ_sort_kernel re-orders dense objects): (pixel bbox, nearest depth key, record index)
+    *scan_row = make_uint4(t.bbox.x, t.bbox.y, t.bbox.z, (uint32_t)pos);
 }
 
 // union pixel bbox and smallest depth key of every 64-entry chunk of the scan order (two-level scan)
@@ -390,81 +392,30 @@ struct CamRT {
     float R[9], T[3], dRe[9], dTe[3], dRa[9], dTa[3];
 };
 
+// world-space vertex k of face f: pool vertex + object offset in f32 (environment.py:148,171)
+__device__ __forceinline__ void world_vertex(const int* __restrict__ pool_faces, const float* __restrict__ pool_verts,
+                                             int vo, int fo, int f, int k, float ox, float oy, float oz, float* w) {
+    const int vi = pool_faces[(size_t)(fo + f) * 3 + k];
+    const float* pv = pool_verts + (size_t)(vo + vi) * 3;
+    w[0] = pv[0] + ox;
+    w[1] = pv[1] + oy;
+    w[2] = pv[2] + oz;
+}
+
 template <bool GRAD>
-__device__ __forceinline__ void view_vertex(const OccScene& sc, const CamRT& c, int vo, int fo, int f, int k, float ox,
-                                            float oy, float oz, VVert& q) {
-    const int vi = sc.pool_faces[(size_t)(fo + f) * 3 + k];
-    const float* pv = sc.pool_verts + (size_t)(vo + vi) * 3;
-    // environment.py:148,171: verts + offset in f32
-    const float wx = pv[0] + ox, wy = pv[1] + oy, wz = pv[2] + oz;
+__device__ __forceinline__ void view_from_world(const CamRT& c, const float* w, VVert& q) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        q.v[j] = wx * c.R[j] + wy * c.R[3 + j] + wz * c.R[6 + j] + c.T[j];
+        q.v[j] = w[0] * c.R[j] + w[1] * c.R[3 + j] + w[2] * c.R[6 + j] + c.T[j];
         if (GRAD) {
-            q.de[j] = wx * c.dRe[j] + wy * c.dRe[3 + j] + wz * c.dRe[6 + j] + c.dTe[j];
-            q.da[j] = wx * c.dRa[j] + wy * c.dRa[3 + j] + wz * c.dRa[6 + j] + c.dTa[j];
+            q.de[j] = w[0] * c.dRe[j] + w[1] * c.dRe[3 + j] + w[2] * c.dRe[6 + j] + c.dTe[j];
+            q.da[j] = w[0] * c.dRa[j] + w[1] * c.dRa[3 + j] + w[2] * c.dRa[6 + j] + c.dTa[j];
         }
     }
 }
 
-// Faces that straddle z = kZClip ([P3D] clip_faces cases 3 and 4, SURVEY A.3).  Rare (the camera must be within
-// ~0.5 of the geometry), so this lives out of line: it re-derives everything from the face index, both when the
-// face is counted and when its records are written, and keeps its dynamically indexed arrays off the hot path.
 template <bool GRAD>
-__device__ __attribute__((noinline)) int clip_face_slow(const OccScene& sc, const CamRT& c, int vo, int fo, int f, float ox,
-                                                        float oy, float oz, Tri* out, int* flags) {
-    VVert q[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) view_vertex<GRAD>(sc, c, vo, fo, f, k, ox, oy, oz, q[k]);
-    const bool b0 = q[0].v[2] < kZClip, b1 = q[1].v[2] < kZClip, b2 = q[2].v[2] < kZClip;
-    const int nb = (int)b0 + (int)b1 + (int)b2;
-    flags[0] = flags[1] = FLAG_CLIPPED;
-    if (nb == 2) {
-        // case 3: p1 = the vertex in front; new triangle (p4, p5, p1)
-        const int i1 = !b0 ? 0 : (!b1 ? 1 : 2);
-        const int i2 = (i1 + 1) % 3, i3 = (i1 + 2) % 3;
-        out[0].v[0] = cut_edge<GRAD>(q[i1], q[i2]);
-        out[0].v[1] = cut_edge<GRAD>(q[i1], q[i3]);
-        out[0].v[2] = project<GRAD>(q[i1]);
-        return finish_tri(out[0], sc.img) ? 1 : 0;
-    }
-    if (nb == 1) {
-        // case 4: p1 = the vertex behind; quad -> (p4, p2, p5), (p5, p2, p3)
-        const int i1 = b0 ? 0 : (b1 ? 1 : 2);
-        const int i2 = (i1 + 1) % 3, i3 = (i1 + 2) % 3;
-        const PVert p4 = cut_edge<GRAD>(q[i1], q[i2]);
-        const PVert p5 = cut_edge<GRAD>(q[i1], q[i3]);
-        const PVert p2 = project<GRAD>(q[i2]);
-        const PVert p3 = project<GRAD>(q[i3]);
-        Tri ta, tb;
-        ta.v[0] = p4; ta.v[1] = p2; ta.v[2] = p5;
-        tb.v[0] = p5; tb.v[1] = p2; tb.v[2] = p3;
-        const bool oka = finish_tri(ta, sc.img), okb = finish_tri(tb, sc.img);
-        if (oka && okb) {
-            out[0] = ta; out[1] = tb;
-            flags[0] = FLAG_PAIR_FIRST | FLAG_CLIPPED; flags[1] = FLAG_PAIR_SECOND | FLAG_CLIPPED;
-            return 2;
-        }
-        if (oka) { out[0] = ta; return 1; }
-        if (okb) { out[0] = tb; return 1; }
-    }
-    return 0;  // nb == 3: the whole face is behind the clip plane
-}
-
-template <bool GRAD>
-__global__ __launch_bounds__(256) void occ_setup_kernel(OccScene sc, const float* __restrict__ cam, OccWorkspace ws) {
-    __shared__ int s_wcnt[4];
-    __shared__ int s_rect[4];
-    const int eo = blockIdx.x;  // env*3 + object
-    const int env = eo / 3;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int mesh = sc.scene_mesh[eo];
-    const int vo = sc.mesh_vert_off[mesh];
-    const int fo = sc.mesh_face_off[mesh];
-    const int nF = sc.mesh_face_off[mesh + 1] - fo;
-    const float ox = sc.scene_offset[eo * 3], oy = sc.scene_offset[eo * 3 + 1], oz = sc.scene_offset[eo * 3 + 2];
-    const float* __restrict__ c = cam + (size_t)env * OCC_CAM_STRIDE;
-    CamRT C;
+__device__ __forceinline__ void load_camera(const float* __restrict__ c, CamRT& C) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         C.R[i] = c[C_R + i];
@@ -477,6 +428,79 @@ __global__ __launch_bounds__(256) void occ_setup_kernel(OccScene sc, const float
         C.dTe[i] = GRAD ? c[C_DT_EL + i] : 0.f;
         C.dTa[i] = GRAD ? c[C_DT_AZ + i] : 0.f;
     }
+}
+
+// Faces that straddle z = kZClip ([P3D] clip_faces cases 3 and 4, SURVEY A.3).  Rare (the camera must be within
+// ~0.5 of the geometry), so this lives out of line: it re-derives everything from the face index, both when the
+// face is counted and when its records are written, and keeps its dynamically indexed arrays off the hot path.
+// Everything arrives by value (the camera is re-read from memory) so that nothing of the caller's state has its
+// address taken - that would pin the kernel arguments and the camera in scratch for the fast path as well.
+template <bool GRAD>
+__device__ __attribute__((noinline)) int clip_face_slow(const int* __restrict__ pool_faces, const float* __restrict__ pool_verts,
+                                                        const float* __restrict__ camp, int S, int vo, int fo, int f,
+                                                        float ox, float oy, float oz, Tri* out, int* flags) {
+    CamRT c;
+    load_camera<GRAD>(camp, c);
+    VVert q[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float w[3];
+        world_vertex(pool_faces, pool_verts, vo, fo, f, k, ox, oy, oz, w);
+        view_from_world<GRAD>(c, w, q[k]);
+    }
+    const bool b0 = q[0].v[2] < kZClip, b1 = q[1].v[2] < kZClip, b2 = q[2].v[2] < kZClip;
+    const int nb = (int)b0 + (int)b1 + (int)b2;
+    flags[0] = flags[1] = FLAG_CLIPPED;
+    if (nb == 2) {
+        // case 3: p1 = the vertex in front; new triangle (p4, p5, p1)
+        const int i1 = !b0 ? 0 : (!b1 ? 1 : 2);
+        const int i2 = (i1 + 1) % 3, i3 = (i1 + 2) % 3;
+        out[0].v[0] = cut_edge<GRAD>(q[i1], q[i2]);
+        out[0].v[1] = cut_edge<GRAD>(q[i1], q[i3]);
+        out[0].v[2] = project<GRAD>(q[i1]);
+        return finish_tri(out[0], S) ? 1 : 0;
+    }
+    if (nb == 1) {
+        // case 4: p1 = the vertex behind; quad -> (p4, p2, p5), (p5, p2, p3)
+        const int i1 = b0 ? 0 : (b1 ? 1 : 2);
+        const int i2 = (i1 + 1) % 3, i3 = (i1 + 2) % 3;
+        const PVert p4 = cut_edge<GRAD>(q[i1], q[i2]);
+        const PVert p5 = cut_edge<GRAD>(q[i1], q[i3]);
+        const PVert p2 = project<GRAD>(q[i2]);
+        const PVert p3 = project<GRAD>(q[i3]);
+        Tri ta, tb;
+        ta.v[0] = p4; ta.v[1] = p2; ta.v[2] = p5;
+        tb.v[0] = p5; tb.v[1] = p2; tb.v[2] = p3;
+        const bool oka = finish_tri(ta, S), okb = finish_tri(tb, S);
+        if (oka && okb) {
+            out[0] = ta; out[1] = tb;
+            flags[0] = FLAG_PAIR_FIRST | FLAG_CLIPPED; flags[1] = FLAG_PAIR_SECOND | FLAG_CLIPPED;
+            return 2;
+        }
+        if (oka) { out[0] = ta; return 1; }
+        if (okb) { out[0] = tb; return 1; }
+    }
+    return 0;  // nb == 3: the whole face is behind the clip plane
+}
+
+template <bool GRAD>
+__global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const float* __restrict__ cam, OccWorkspace ws) {
+    __shared__ int s_wcnt[2][4];  // double-buffered: one barrier per 256-face round
+    __shared__ int s_rect[4];
+    const int eo = blockIdx.x;  // env*3 + object
+    const int env = eo / 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mesh = sc.scene_mesh[eo];
+    const int vo = sc.mesh_vert_off[mesh];
+    const int fo = sc.mesh_face_off[mesh];
+    const int nF = sc.mesh_face_off[mesh + 1] - fo;
+    const float ox = sc.scene_offset[eo * 3], oy = sc.scene_offset[eo * 3 + 1], oz = sc.scene_offset[eo * 3 + 2];
+    const float* __restrict__ c = cam + (size_t)env * OCC_CAM_STRIDE;
+    CamRT C;
+    load_camera<GRAD>(c, C);
+    const int* __restrict__ pool_faces = sc.pool_faces;
+    const float* __restrict__ pool_verts = sc.pool_verts;
+    const int S = sc.img, rec_cap = sc.rec_cap;
     if (tid == 0) {
         s_rect[0] = 1 << 20;
         s_rect[1] = 1 << 20;
@@ -484,106 +508,135 @@ __global__ __launch_bounds__(256) void occ_setup_kernel(OccScene sc, const float
         s_rect[3] = -1;
     }
     __syncthreads();
-    float* __restrict__ rec = ws.rec + (size_t)eo * sc.rec_cap * OCC_REC_STRIDE;
-    uint4* __restrict__ bbs = reinterpret_cast<uint4*>(ws.rec_bbox) + (size_t)eo * sc.rec_cap;
+    float* __restrict__ rec = ws.rec + (size_t)eo * rec_cap * OCC_REC_STRIDE;
+    uint4* __restrict__ bbs = reinterpret_cast<uint4*>(ws.rec_bbox) + (size_t)eo * rec_cap;
+    uint4* __restrict__ scan = reinterpret_cast<uint4*>(ws.scan) + (size_t)eo * rec_cap;
     int total = 0;
     bool overflow = false;
-    for (int base = 0; base < nF; base += 256) {
+    int rx0 = 1 << 20, ry0 = 1 << 20, rx1 = -1, ry1 = -1;  // this thread's share of the object's block rect
+    int round = 0;
+    for (int base = 0; base < nF; base += 256, round ^= 1) {
         const int f = base + tid;
         int cnt = 0;
         bool slow = false;
-        Tri tri;  // fast path: the unclipped face, positions only until it is known to survive
+        float w0[3], w1[3], w2[3];  // world-space corners: all that a surviving face carries across the barrier
         if (f < nF) {
+            Tri tri;  // fast path: the unclipped face, positions only (recomputed for the survivors below)
             VVert q0, q1, q2;
-            view_vertex<false>(sc, C, vo, fo, f, 0, ox, oy, oz, q0);
-            view_vertex<false>(sc, C, vo, fo, f, 1, ox, oy, oz, q1);
-            view_vertex<false>(sc, C, vo, fo, f, 2, ox, oy, oz, q2);
+            world_vertex(pool_faces, pool_verts, vo, fo, f, 0, ox, oy, oz, w0);
+            world_vertex(pool_faces, pool_verts, vo, fo, f, 1, ox, oy, oz, w1);
+            world_vertex(pool_faces, pool_verts, vo, fo, f, 2, ox, oy, oz, w2);
+            view_from_world<false>(C, w0, q0);
+            view_from_world<false>(C, w1, q1);
+            view_from_world<false>(C, w2, q2);
             slow = (q0.v[2] < kZClip) || (q1.v[2] < kZClip) || (q2.v[2] < kZClip);
             if (!slow) {
                 tri.v[0] = project<false>(q0);
                 tri.v[1] = project<false>(q1);
                 tri.v[2] = project<false>(q2);
-                cnt = finish_tri(tri, sc.img) ? 1 : 0;
+                cnt = finish_tri(tri, S) ? 1 : 0;
             }
         }
         if (__ballot(slow)) {
             if (slow) {
                 Tri tmp[2];
                 int fl[2];
-                cnt = clip_face_slow<GRAD>(sc, C, vo, fo, f, ox, oy, oz, tmp, fl);
+                cnt = clip_face_slow<GRAD>(pool_faces, pool_verts, c, S, vo, fo, f, ox, oy, oz, tmp, fl);
             }
         }
         // ordered compaction: exclusive prefix of cnt in {0,1,2} over the block
         const unsigned long long m1 = __ballot(cnt >= 1), m2 = __ballot(cnt == 2);
         const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
         const int pre = __popcll(m1 & lt) + __popcll(m2 & lt);
-        if (lane == 0) s_wcnt[wave] = __popcll(m1) + __popcll(m2);
+        if (lane == 0) s_wcnt[round][wave] = __popcll(m1) + __popcll(m2);
         __syncthreads();
         int woff = 0, itot = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const int cw = s_wcnt[w];
+            const int cw = s_wcnt[round][w];
             if (w < wave) woff += cw;
             itot += cw;
         }
         const int pos = total + woff + pre;
         if (cnt >= 1) {
-            if (pos + cnt <= sc.rec_cap) {
+            if (pos + cnt <= rec_cap) {
                 int x0, y0, x1, y1;
                 if (!slow) {
-                    if (GRAD) {
-                        // tangents only for the faces that survived culling
+                    Tri tri;
+                    {
                         VVert q;
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            view_vertex<true>(sc, C, vo, fo, f, k, ox, oy, oz, q);
-                            const PVert pk = project<true>(q);
-                            tri.v[k].t[0] = pk.t[0]; tri.v[k].t[1] = pk.t[1]; tri.v[k].t[2] = pk.t[2]; tri.v[k].t[3] = pk.t[3];
-                        }
+                        view_from_world<false>(C, w0, q);
+                        tri.v[0] = project<false>(q);
+                        view_from_world<false>(C, w1, q);
+                        tri.v[1] = project<false>(q);
+                        view_from_world<false>(C, w2, q);
+                        tri.v[2] = project<false>(q);
+                        finish_tri(tri, S);
                     }
-                    write_record<GRAD>(rec + (size_t)pos * OCC_REC_STRIDE, bbs + pos, tri, f, 0);
+                    float* __restrict__ r = rec + (size_t)pos * OCC_REC_STRIDE;
+                    write_record<false>(r, bbs + pos, scan + pos, pos, tri, f, 0);
+                    if (GRAD) {
+                        // tangents only for the faces that survived culling, stored vertex by vertex
+                        VVert q;
+                        PVert pk;
+                        view_from_world<true>(C, w0, q);
+                        pk = project<true>(q);
+                        reinterpret_cast<float4*>(r)[6] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
+                        view_from_world<true>(C, w1, q);
+                        pk = project<true>(q);
+                        reinterpret_cast<float4*>(r)[7] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
+                        view_from_world<true>(C, w2, q);
+                        pk = project<true>(q);
+                        reinterpret_cast<float4*>(r)[8] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
+                    }
                     x0 = tri.tx0; y0 = tri.ty0; x1 = tri.tx1; y1 = tri.ty1;
                 } else {
                     Tri tmp[2];
                     int fl[2];
-                    clip_face_slow<GRAD>(sc, C, vo, fo, f, ox, oy, oz, tmp, fl);
-                    write_record<GRAD>(rec + (size_t)pos * OCC_REC_STRIDE, bbs + pos, tmp[0], f, fl[0]);
+                    clip_face_slow<GRAD>(pool_faces, pool_verts, c, S, vo, fo, f, ox, oy, oz, tmp, fl);
+                    write_record<GRAD>(rec + (size_t)pos * OCC_REC_STRIDE, bbs + pos, scan + pos, pos, tmp[0], f, fl[0]);
                     x0 = tmp[0].tx0; y0 = tmp[0].ty0; x1 = tmp[0].tx1; y1 = tmp[0].ty1;
                     if (cnt == 2) {
-                        write_record<GRAD>(rec + (size_t)(pos + 1) * OCC_REC_STRIDE, bbs + pos + 1, tmp[1], f, fl[1]);
+                        write_record<GRAD>(rec + (size_t)(pos + 1) * OCC_REC_STRIDE, bbs + pos + 1, scan + pos + 1, pos + 1,
+                                           tmp[1], f, fl[1]);
                         x0 = min(x0, tmp[1].tx0); y0 = min(y0, tmp[1].ty0);
                         x1 = max(x1, tmp[1].tx1); y1 = max(y1, tmp[1].ty1);
                     }
                 }
-                atomicMin(&s_rect[0], x0);
-                atomicMin(&s_rect[1], y0);
-                atomicMax(&s_rect[2], x1);
-                atomicMax(&s_rect[3], y1);
+                rx0 = min(rx0, x0); ry0 = min(ry0, y0);
+                rx1 = max(rx1, x1); ry1 = max(ry1, y1);
             } else {
                 overflow = true;
             }
         }
         total += itot;
-        __syncthreads();
     }
     if (overflow) atomicOr(&ws.status[env], OCC_STATUS_REC_OVERFLOW);
+    // object block rect: wave reduction, then one LDS atomic per wave
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        rx0 = min(rx0, __shfl_xor(rx0, m, 64));
+        ry0 = min(ry0, __shfl_xor(ry0, m, 64));
+        rx1 = max(rx1, __shfl_xor(rx1, m, 64));
+        ry1 = max(ry1, __shfl_xor(ry1, m, 64));
+    }
+    if (lane == 0) {
+        atomicMin(&s_rect[0], rx0);
+        atomicMin(&s_rect[1], ry0);
+        atomicMax(&s_rect[2], rx1);
+        atomicMax(&s_rect[3], ry1);
+    }
     {
-        // SCAN ORDER of the raster kernel: (pixel bbox, key of the nearest vertex depth, record index) rows, in
-        // face order here (mesh order is spatially coherent, which makes the chunk boxes selective);
+        // SCAN ORDER of the raster kernel: (pixel bbox, key of the nearest vertex depth, record index) rows, written
+        // with the records in face order (mesh order is spatially coherent, which makes the chunk boxes selective);
         // occ_sort_kernel re-orders dense objects front to back.  The depth keys make the raster kernel's
         // pruning exact in ANY order; the order only decides how early it bites.
-        const int nr = min(total, sc.rec_cap);
-        uint4* __restrict__ scan = reinterpret_cast<uint4*>(ws.scan) + (size_t)eo * sc.rec_cap;
-        __syncthreads();  // bbs[] of the whole object written
-        for (int i = tid; i < nr; i += 256) {
-            const uint4 bb = bbs[i];
-            scan[i] = make_uint4(bb.x, bb.y, bb.z, (uint32_t)i);
-        }
-        __syncthreads();
-        chunk_boxes(scan, reinterpret_cast<uint4*>(ws.rec_cbox) + (size_t)eo * ((sc.rec_cap + 63) >> 6), nr, wave, lane);
+        const int nr = min(total, rec_cap);
+        __syncthreads();  // scan[] of the whole object written (and s_rect complete)
+        chunk_boxes(scan, reinterpret_cast<uint4*>(ws.rec_cbox) + (size_t)eo * ((rec_cap + 63) >> 6), nr, wave, lane);
     }
     if (tid == 0) {
-        ws.nrec[eo] = min(total, sc.rec_cap);
+        ws.nrec[eo] = min(total, rec_cap);
         ws.objrect[eo * 4 + 0] = s_rect[0];
         ws.objrect[eo * 4 + 1] = s_rect[1];
         ws.objrect[eo * 4 + 2] = s_rect[2];
