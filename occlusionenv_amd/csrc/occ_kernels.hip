@@ -487,6 +487,7 @@ template <bool GRAD>
 __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const float* __restrict__ cam, OccWorkspace ws) {
     __shared__ int s_wcnt[2][4];  // double-buffered: one barrier per 256-face round
     __shared__ int s_rect[4];
+    __shared__ float4 s_rec[4 * 64 * 9];  // per wave: the records of one round, staged for coalesced stores
     const int eo = blockIdx.x;  // env*3 + object
     const int env = eo / 3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -558,6 +559,12 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
             itot += cw;
         }
         const int pos = total + woff + pre;
+        // Records of a wave are consecutive (ordered compaction): the survivors put theirs into LDS and the wave
+        // copies the block out with full-width 16-byte stores (a lane writing its own 144-byte record straight to
+        // memory touches nine cache lines that 7 other lanes also write).  Waves with a z-clipped face, or at the
+        // capacity limit, store directly.
+        const int wstart = total + woff, nw = __popcll(m1) + __popcll(m2);
+        const bool staged = (__ballot(slow) == 0ull) && (wstart + nw <= rec_cap);
         if (cnt >= 1) {
             if (pos + cnt <= rec_cap) {
                 int x0, y0, x1, y1;
@@ -573,21 +580,27 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
                         tri.v[2] = project<false>(q);
                         finish_tri(tri, S);
                     }
-                    float* __restrict__ r = rec + (size_t)pos * OCC_REC_STRIDE;
-                    write_record<false>(r, bbs + pos, scan + pos, pos, tri, f, 0);
-                    if (GRAD) {
-                        // tangents only for the faces that survived culling, stored vertex by vertex
-                        VVert q;
-                        PVert pk;
-                        view_from_world<true>(C, w0, q);
-                        pk = project<true>(q);
-                        reinterpret_cast<float4*>(r)[6] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
-                        view_from_world<true>(C, w1, q);
-                        pk = project<true>(q);
-                        reinterpret_cast<float4*>(r)[7] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
-                        view_from_world<true>(C, w2, q);
-                        pk = project<true>(q);
-                        reinterpret_cast<float4*>(r)[8] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
+                    auto emit = [&](float* __restrict__ r) {
+                        write_record<false>(r, bbs + pos, scan + pos, pos, tri, f, 0);
+                        if (GRAD) {
+                            // tangents only for the faces that survived culling, stored vertex by vertex
+                            VVert q;
+                            PVert pk;
+                            view_from_world<true>(C, w0, q);
+                            pk = project<true>(q);
+                            reinterpret_cast<float4*>(r)[6] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
+                            view_from_world<true>(C, w1, q);
+                            pk = project<true>(q);
+                            reinterpret_cast<float4*>(r)[7] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
+                            view_from_world<true>(C, w2, q);
+                            pk = project<true>(q);
+                            reinterpret_cast<float4*>(r)[8] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
+                        }
+                    };
+                    if (staged) {
+                        emit(reinterpret_cast<float*>(&s_rec[(wave * 64 + pre) * 9]));
+                    } else {
+                        emit(rec + (size_t)pos * OCC_REC_STRIDE);
                     }
                     x0 = tri.tx0; y0 = tri.ty0; x1 = tri.tx1; y1 = tri.ty1;
                 } else {
@@ -608,6 +621,19 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
             } else {
                 overflow = true;
             }
+        }
+        if (staged) {  // wave-uniform
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            constexpr int kP = GRAD ? 9 : 6;  // parts this variant writes
+            float4* __restrict__ dst = reinterpret_cast<float4*>(rec + (size_t)wstart * OCC_REC_STRIDE);
+            const float4* src = &s_rec[wave * 64 * 9];
+            for (int i = lane; i < nw * kP; i += 64) {
+                const int rj = i / kP, part = i - rj * kP;
+                dst[rj * 9 + part] = src[rj * 9 + part];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         total += itot;
     }
