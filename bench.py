@@ -33,11 +33,12 @@ def b_alg_bytes(vf_sum: float, S: int) -> float:
 
 
 def build_env(workload: str, n_env: int, img: int, seed: int):
-    from occlusionenv_amd.environment import OcclusionEnv
+    from occlusionenv_amd.environment import OcclusionEnv, seed_scene_rng
     from occlusionenv_amd.meshes import SyntheticShapeNet
     from occlusionenv_amd.SubProcVecEnv import SimpleVecEnv
 
     np.random.seed(seed)
+    seed_scene_rng(seed)  # model draws of the auto-reset scenes: reproducible runs
     if workload == "teapot":
         ds = None
     else:

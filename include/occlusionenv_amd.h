@@ -19,7 +19,8 @@
  *     PyTorch3D layout, naive path)                                 -> occ_rasterize_meshes_naive,
  *                                                                      occ_rasterize_meshes_backward_dists
  *   - SimpleVecEnv.step_wait's per-step host hand-off and auto-reset (SubProcVecEnv.py:209-218)
- *                                                                   -> occ_step_flags, occ_reset_commit
+ *                                                                   -> occ_step_flags, occ_reset_commit,
+ *                                                                      occ_auto_reset, occ_reserve_refill
  *
  * Conventions: plain pointers and sizes only; every pointer is DEVICE memory owned by the
  * caller (PyTorch's ROCm allocator in the Python host); calls are asynchronous on `stream`
@@ -196,6 +197,51 @@ int occ_step_flags(const uint8_t* done, const float* loss_all, const int32_t* st
 int occ_reset_commit(const int32_t* pairs, int n, float* el, float* az, float* radius, float* campos, float* cam,
                      float* alphas, float* full_reward, float* object_mass, int32_t* scene_mesh, float* scene_offset,
                      float* obs, const float* obs_all, const float* loss_all, int img, void* stream);
+
+/*
+ * Device-side auto-reset (the whole of "if buf_done: obs = self.envs[env_idx].reset()", SubProcVecEnv.py:209-218,
+ * incl. reset()'s rejection loop environment.py:288-327) for a batched step whose launch also rendered n_reserve
+ * speculative reset scenes (rows n_env .. n_env+n_reserve-1 of every *_all array, reset camera).
+ *
+ * Reserve slot life cycle (rs_state): OCC_RS_EMPTY -- host uploads a scene (occ_reserve_refill) --> OCC_RS_PENDING
+ * -- rendered by a step; loss > 0.1 or 10th try --> OCC_RS_READY (else back to EMPTY, try count kept) -- taken by
+ * a finished env --> EMPTY (tries = 0).  Only the host leaves EMPTY, only the device leaves PENDING / READY.
+ *
+ * One call = two launches: (1) a single block ages the PENDING slots, lists finished envs and READY slots in
+ * index order and pairs them; (2) every pair copies the slot's state into the env's rows (as occ_reset_commit),
+ * saving the env's final observation to term_obs[slot] first (info["terminal_observation"]).
+ * report (n_env + 2*n_reserve + 2 int32): [0,n_env) done | [n_env, +n_reserve) slot state AFTER the call |
+ * [.., +n_reserve) env that took the slot this call or -1 | any status bit | finished envs left without a slot.
+ * pairs: scratch, 2 + 2*n_reserve int32.  Arrays of OccEnvState hold n_env + n_reserve rows except
+ * campos / full_reward / object_mass (n_env rows); obs_all has n_env + n_reserve rows.
+ */
+#define OCC_RS_EMPTY 0
+#define OCC_RS_PENDING 1
+#define OCC_RS_READY 2
+
+typedef struct OccEnvState {
+    float* el;
+    float* az;
+    float* radius;
+    float* campos;
+    float* cam;
+    float* alphas;
+    float* full_reward;
+    float* object_mass;
+    int32_t* scene_mesh;
+    float* scene_offset;
+} OccEnvState;
+
+int occ_auto_reset(const uint8_t* done, const float* loss_all, const int32_t* status, int n_env, int n_reserve,
+                   int32_t* rs_state, int32_t* rs_tries, const OccEnvState* st, float* obs_all, float* term_obs, int img,
+                   int32_t* pairs, int32_t* report, void* stream);
+
+/*
+ * Host -> reserve: n packed rows of 13 words (slot, mesh id x3, offset x9 as float bits) already in device
+ * memory; scatters them into scene_mesh / scene_offset rows n_env + slot and marks the slots OCC_RS_PENDING.
+ */
+int occ_reserve_refill(const int32_t* packed, int n, int n_env, int n_reserve, int32_t* scene_mesh, float* scene_offset,
+                       int32_t* rs_state, void* stream);
 
 /*
  * Measurement hooks (bench.py only; not part of the reference surface).  While enabled, occ_render

@@ -24,6 +24,7 @@ from typing import Sequence
 import numpy as np
 import torch
 
+from . import _native as nat
 from .baseVecEnv import VecEnv
 from .engine import OcclusionEngine
 from .environment import shared_pool
@@ -75,10 +76,11 @@ class _LazyInfos(Sequence):
     """``list[dict]`` look-alike whose dicts are built on first access (1024 dicts of tensor views per step
     would cost more host time than the render)."""
 
-    def __init__(self, engine, full_state, loss):
+    def __init__(self, engine, full_state, loss, resolve=None):
         self._e, self._fs, self._loss = engine, full_state, loss
         self._extra = {}
         self._made = {}
+        self._resolve = resolve  # called before the first read: lets the env finish its deferred bookkeeping
 
     def __len__(self):
         return self._fs.shape[0]
@@ -95,6 +97,9 @@ class _LazyInfos(Sequence):
             i += len(self)
         if not 0 <= i < len(self):
             raise IndexError(i)
+        if self._resolve is not None:
+            r, self._resolve = self._resolve, None
+            r()
         if i not in self._made:
             d = {"full_state": self._fs[i:i + 1], "position": self._e.camera_position[i],
                  "full_reward": self._loss[i]}
@@ -120,15 +125,18 @@ class SimpleVecEnv(VecEnv):
         for i, e in enumerate(self.envs):
             e._attach(self.engine, i)
         self._rs_scene = [None] * reserve   # scene assigned to each reserve slot
-        self._rs_tries = [0] * reserve      # rejection-loop tries spent on the slot's current reset (environment.py:288)
-        self._rs_ready = [False] * reserve  # slot holds an accepted reset scene, rendered by the last step
+        # slot states live on the device (occ_auto_reset); this is the host's copy as of the last report it read
+        self._rs_state = np.zeros(reserve, dtype=np.int32)
+        self._pending = None                # (report handle, obs, out, infos) of the last step, not yet read
+        self._late = []                     # slots refilled AFTER the pairing of the step whose report is pending
+        self._warm = False
 
     def step_async(self, actions):
         self.actions = actions
 
     def _refill_reserve(self, slots):
-        """Draw a new candidate scene for the given reserve slots (host) and upload them in one copy."""
-        if not slots:
+        """Draw a new candidate scene for the given (EMPTY) reserve slots on the host and hand them to the device."""
+        if not len(slots):
             return
         from .environment import sample_scene
 
@@ -143,29 +151,74 @@ class SimpleVecEnv(VecEnv):
                 if max(pool.num_faces(m) for m in ids) <= 250000:  # environment.py:296-298
                     break
             self._rs_scene[r] = (ids, offs)
-            self._rs_ready[r] = False
-        self.engine.set_reserve_scenes(slots, [self._rs_scene[r][0] for r in slots], [self._rs_scene[r][1] for r in slots])
+            self._rs_state[r] = nat.RS_PENDING
+        self.engine.refill_reserve(slots, [self._rs_scene[r][0] for r in slots], [self._rs_scene[r][1] for r in slots])
 
     def _warm_reserve(self):
         """Run the reset rejection loop for every reserve slot that does not hold an accepted scene yet (batched,
-        synchronous).  Called from reset() and before the first step so that steady state starts at once; afterwards
-        the loop advances one try per step inside the step launches."""
+        synchronous, host-driven).  Called from reset() and before the first step so that steady state starts at
+        once; afterwards the loop advances one try per step inside the step launches, on the device."""
+        self._drain()
         eng, R = self.engine, self.engine.R
-        pending = [r for r in range(R) if not self._rs_ready[r]]
-        self._refill_reserve([r for r in pending if self._rs_scene[r] is None])
+        pending = [r for r in range(R) if self._rs_state[r] != nat.RS_READY]
+        self._refill_reserve([r for r in pending if self._rs_scene[r] is None or self._rs_state[r] == nat.RS_EMPTY])
+        tries = {r: 0 for r in pending}
         while pending:
             res = eng.evaluate_scenes([self._rs_scene[r][0] for r in pending], [self._rs_scene[r][1] for r in pending],
                                       4.0, 0.0, 0.0)
             ok = (res["loss"] > 0.1).cpu().tolist()
             redraw = []
             for j, r in enumerate(pending):
-                self._rs_tries[r] += 1
-                if ok[j] or self._rs_tries[r] >= 10:
-                    self._rs_ready[r] = True
-                else:
+                tries[r] += 1
+                if not (ok[j] or tries[r] >= 10):
                     redraw.append(r)
             self._refill_reserve(redraw)
             pending = redraw
+        self._rs_state[:] = nat.RS_READY
+        eng.set_reserve_state(self._rs_state, np.zeros(R, dtype=np.int32))
+        self._warm = True
+
+    def _drain(self, defer_refill=False):
+        """Read the auto-reset report of the last step (the ONE host sync per batched step, taken as late as
+        possible: at the start of the next step or when infos are first read) and do the host's share: scene
+        bookkeeping of the envs that were reset, terminal observations, new candidate scenes for the slots the
+        device emptied, and the synchronous fallback if the reserve ran dry.  With ``defer_refill`` the EMPTY
+        slots are returned instead of refilled (step_wait refills them after it has launched the next step)."""
+        if self._pending is None:
+            return []
+        pend, obs, out, infos = self._pending
+        self._pending = None
+        infos._resolve = None
+        eng, N, R = self.engine, self.num_envs, self.engine.R
+        pend["event"].synchronize()
+        rep = pend["report_host"].numpy()
+        if rep[N + 2 * R]:
+            eng.check_status()
+        state = rep[N:N + R].copy()
+        assign = rep[N + R:N + 2 * R]
+        taken = np.nonzero(assign >= 0)[0]
+        for r in taken.tolist():
+            i = int(assign[r])
+            # save final observation where user can get it, then reset (SubProcVecEnv.py:211-214)
+            infos.set(i, "terminal_observation", pend["term"][r:r + 1])
+            self.envs[i]._scene = self._rs_scene[r]
+            self.envs[i].image = out["full_state_all"][N + r:N + r + 1]
+        if rep[N + 2 * R + 1]:  # reserve exhausted: synchronous batched reset for the rest
+            done_envs = set(np.nonzero(rep[:N])[0].tolist())
+            left = sorted(done_envs - set(int(assign[r]) for r in taken.tolist()))
+            term = obs[left].clone()
+            for j, i in enumerate(left):
+                infos.set(i, "terminal_observation", term[j:j + 1])
+            obs[left] = self._reset_envs(left, torch.zeros(len(left)))[:, 0]
+        # slots refilled after this report's pairing ran still read EMPTY in it: they are PENDING by now
+        state[self._late] = nat.RS_PENDING
+        self._late = []
+        self._rs_state = state
+        empty = np.nonzero(state == nat.RS_EMPTY)[0].tolist()
+        if defer_refill:
+            return empty
+        self._refill_reserve(empty)
+        return []
 
     def step_wait(self):
         eng = self.engine
@@ -175,55 +228,37 @@ class SimpleVecEnv(VecEnv):
         if actions.device != eng.device:
             actions = actions.to(eng.device)
         R, N = eng.R, self.num_envs
-        if R and self._rs_scene[0] is None:
-            self._warm_reserve()
         if R:
+            if not self._warm:
+                self._warm_reserve()
+            empty = self._drain(defer_refill=True)
             obs, rewards, dones, full_state, loss, out = eng.step(actions, with_reserve=True)
-            flags = eng.step_flags(out["done_u8"], out["loss_all"])
-        else:
-            obs, rewards, dones, full_state, loss = eng.step(actions)
-            flags = eng.step_flags(dones.to(torch.uint8), None)
+            # finished envs are reset ON THE DEVICE from the reserve (pairing + commit); the host reads the
+            # report later (_drain).  NB out["obs_all"][:N] IS obs: the commit writes the reset observation in place
+            pend = eng.auto_reset(out)
+            infos = _LazyInfos(eng, full_state, loss, resolve=self._drain)
+            self._pending = (pend, obs, out, infos)
+            # new candidate scenes for the slots emptied one step ago: off the critical path (the GPU is busy
+            # with this step); they are rendered from the next step on
+            self._refill_reserve(empty)
+            self._late = empty
+            # few accepted scenes left (as far as the host knows): do not run ahead, the fallback must come first
+            if int((self._rs_state == nat.RS_READY).sum()) < max(2, R // 2):
+                self._drain()
+            return obs, rewards, dones, infos
+        obs, rewards, dones, full_state, loss = eng.step(actions)
+        flags = eng.step_flags(dones.to(torch.uint8), None)
         infos = _LazyInfos(eng, full_state, loss)
-        # ONE host sync per batched step: which envs finished, which reserve scenes pass the reset test
-        # (loss > 0.1, environment.py:327), kernel status words
         fl = flags.cpu().numpy()
         if fl[-1]:
             eng.check_status()
-        refill = []
-        if R:
-            ok = fl[N:N + R]
-            for r in range(R):  # every slot was rendered by this launch with its current scene
-                if self._rs_ready[r]:
-                    continue
-                self._rs_tries[r] += 1
-                if ok[r] or self._rs_tries[r] >= 10:  # accept, or keep the 10th try regardless (environment.py:327)
-                    self._rs_ready[r] = True
-                else:
-                    refill.append(r)
         fin_l = np.nonzero(fl[:N])[0].tolist()
         if fin_l:
             # save final observation where user can get it, then reset (SubProcVecEnv.py:211-214)
             term = obs[fin_l].clone()
             for j, i in enumerate(fin_l):
                 infos.set(i, "terminal_observation", term[j:j + 1])
-            take, left = [], []
-            ready = [r for r in range(R) if self._rs_ready[r]]
-            for i in fin_l:
-                if ready:
-                    take.append((i, ready.pop()))
-                else:
-                    left.append(i)
-            if take:
-                # NB out["obs_all"][:N] IS obs: the commit kernel writes the reset observation in place
-                eng.commit_from_reserve([i for i, _ in take], [r for _, r in take], out)
-                for i, r in take:
-                    self.envs[i]._scene = self._rs_scene[r]
-                    self.envs[i].image = out["full_state_all"][N + r:N + r + 1]
-                    self._rs_tries[r] = 0
-                    refill.append(r)
-            if left:  # reserve exhausted: synchronous batched reset for the rest
-                obs[left] = self._reset_envs(left, torch.zeros(len(left)))[:, 0]
-        self._refill_reserve(refill)
+            obs[fin_l] = self._reset_envs(fin_l, torch.zeros(len(fin_l)))[:, 0]
         return obs, rewards, dones, infos
 
     def seed(self, seed=None):
@@ -235,6 +270,7 @@ class SimpleVecEnv(VecEnv):
         (environment.py:288-327).  Here every round draws several candidate scenes per pending env on the host
         (in try order), renders ALL candidates in one launch sequence, and each env takes its first accepted
         candidate -- the same outcome per env as trying them one by one, in far fewer GPU round trips."""
+        self._drain()
         eng, N = self.engine, self.num_envs
         az = torch.as_tensor(az, dtype=torch.float32).reshape(-1)
         pos = {i: j for j, i in enumerate(indices)}
@@ -315,4 +351,5 @@ class SimpleVecEnv(VecEnv):
         return [getattr(env_i, method_name)(*method_args, **method_kwargs) for env_i in self._get_target_envs(indices)]
 
     def _get_target_envs(self, indices):
+        self._drain()  # the env objects' scene bookkeeping must be current
         return [self.envs[i] for i in self._get_indices(indices)]

@@ -97,6 +97,13 @@ class OccRenderOut(C.Structure):
     ]
 
 
+class OccEnvState(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("el", "az", "radius", "campos", "cam", "alphas", "full_reward", "object_mass",
+                                          "scene_mesh", "scene_offset")]
+
+
+RS_EMPTY, RS_PENDING, RS_READY = 0, 1, 2
+
 #: every symbol include/occlusionenv_amd.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "occ_abi_version": (C.c_int, []),
@@ -113,6 +120,9 @@ SYMBOLS = {
                                                       C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "occ_step_flags": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "occ_reset_commit": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 13 + [C.c_int, C.c_void_p]),
+    "occ_auto_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.POINTER(OccEnvState), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "occ_reserve_refill": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "occ_profile_enable": (C.c_int, [C.c_int]),
     "occ_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }

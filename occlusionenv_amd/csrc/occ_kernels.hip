@@ -261,17 +261,20 @@ struct Tri {
     int tx0, ty0, tx1, ty1;
 };
 
-// returns false if the triangle can never be matched to a pixel (culled / degenerate / off screen)
+// Returns false if the triangle can never be matched to a pixel (culled / degenerate / off screen).  EVERY field
+// is filled with in-range values either way: occ_setup_kernel evaluates a surviving face twice (once to count it,
+// once to write it) and the two inlined copies need not round alike (fp contraction), so the second evaluation
+// must be safe to use even where it would, by a hair, have decided differently.
 __device__ __forceinline__ bool finish_tri(Tri& t, int S) {
     const float x0 = t.v[0].x, y0 = t.v[0].y, x1 = t.v[1].x, y1 = t.v[1].y, x2 = t.v[2].x, y2 = t.v[2].y;
     // [P3D] face_area = EdgeFunction(v0; v1, v2); back faces are culled (environment.py:253,271)
     const float area = (x0 - x1) * (y2 - y1) - (y0 - y1) * (x2 - x1);
-    if (!(area > kEpsilon)) return false;  // back face, zero area or NaN
-    if (fmax3(t.v[0].z, t.v[1].z, t.v[2].z) < 0.0f) return false;
+    bool vis = area > kEpsilon;  // false for a back face, zero area or NaN
+    vis = vis && !(fmax3(t.v[0].z, t.v[1].z, t.v[2].z) < 0.0f);
     const float bx0 = fmin3(x0, x1, x2) - kSqrtBlur, bx1 = fmax3(x0, x1, x2) + kSqrtBlur;
     const float by0 = fmin3(y0, y1, y2) - kSqrtBlur, by1 = fmax3(y0, y1, y2) + kSqrtBlur;
     const float lim = 1.0f - 1.0f / (float)S;  // outermost pixel centre
-    if (bx1 < -lim || bx0 > lim || by1 < -lim || by0 > lim) return false;
+    vis = vis && !(bx1 < -lim || bx0 > lim || by1 < -lim || by0 > lim);
     // pixel index of an NDC coordinate: u(f) = (S-1) - ((f+1)*S - 1)/2   (decreasing)
     const float fS = (float)S;
     auto u = [&](float f) { return (fS - 1.0f) - ((f + 1.0f) * fS - 1.0f) * 0.5f; };
@@ -279,11 +282,11 @@ __device__ __forceinline__ bool finish_tri(Tri& t, int S) {
     // covers the rounding of u() - the per-pixel float test in eval_face stays the authority
     int xl = (int)ceilf(u(bx1) - 1e-3f), xh = (int)floorf(u(bx0) + 1e-3f);
     int yl = (int)ceilf(u(by1) - 1e-3f), yh = (int)floorf(u(by0) + 1e-3f);
-    xl = max(xl, 0);
-    yl = max(yl, 0);
-    xh = min(xh, S - 1);
-    yh = min(yh, S - 1);
-    if (xl > xh || yl > yh) return false;
+    vis = vis && (max(xl, 0) <= min(xh, S - 1)) && (max(yl, 0) <= min(yh, S - 1));
+    xl = min(max(xl, 0), S - 1);
+    yl = min(max(yl, 0), S - 1);
+    xh = min(max(xh, xl), S - 1);
+    yh = min(max(yh, yl), S - 1);
     t.tx0 = xl / OCC_BLOCK;
     t.tx1 = xh / OCC_BLOCK;
     t.ty0 = yl / OCC_BLOCK;
@@ -291,7 +294,7 @@ __device__ __forceinline__ bool finish_tri(Tri& t, int S) {
     const uint32_t zb = __float_as_uint(fmin3(t.v[0].z, t.v[1].z, t.v[2].z));
     t.bbox = make_uint4((uint32_t)xl | ((uint32_t)yl << 16), (uint32_t)xh | ((uint32_t)yh << 16),
                         (zb & 0x80000000u) ? ~zb : (zb | 0x80000000u), 0u);
-    return true;
+    return vis;
 }
 
 template <bool GRAD>
@@ -800,6 +803,27 @@ __device__ __forceinline__ uint32_t px_min_u(uint32_t v) { v = min(v, (uint32_t)
 __device__ __forceinline__ uint32_t px_max_u(uint32_t v) { v = max(v, (uint32_t)__shfl_xor((int)v, 16, 64)); v = max(v, (uint32_t)__shfl_xor((int)v, 32, 64)); return v; }
 __device__ __forceinline__ bool px_any(bool v) { return px_sum_i(v ? 1 : 0) != 0; }
 
+#ifdef OCC_DBG_BOUNDS  // diagnostic build only: index checks at every memory access of the raster kernel
+__device__ int g_dbg_fault[8];
+#define OCC_BOUND(cond, code, v0, v1)                                          \
+    ((cond) ? true                                                             \
+            : ((atomicCAS(&g_dbg_fault[0], 0, (code)) == 0                     \
+                    ? (g_dbg_fault[1] = (int)blockIdx.x, g_dbg_fault[2] = (int)threadIdx.x, g_dbg_fault[3] = (int)(v0), \
+                       g_dbg_fault[4] = (int)(v1), 0)                          \
+                    : 0),                                                      \
+               false))
+#define OCC_WATCHDOG(code, v0, v1)                                              \
+    do {                                                                        \
+        if (++wd_iters > 4000000) {                                             \
+            (void)OCC_BOUND(false, (code), (v0), (v1));                         \
+            return;                                                             \
+        }                                                                       \
+    } while (0)
+#else
+#define OCC_BOUND(cond, code, v0, v1) true
+#define OCC_WATCHDOG(code, v0, v1) do { } while (0)
+#endif
+
 // Exact top-K-by-z for one PIXEL whose candidates sit in the lists of its four lanes (lane g = lane >> 4 holds
 // the candidates of faces g, g+4, ... in face order; entry e = (key(z), 1-p, g_el, g_az) at list[e*64 + lane],
 // the key being the order-preserving integer image of z).  Keeps the K smallest z like [P3D]'s (pz, face) ordering
@@ -824,7 +848,12 @@ __device__ __forceinline__ void topk_select4(float4* __restrict__ list, uint32_t
                                              int cnt, int K, bool active,
                                              uint32_t kmin_own, uint32_t kmax_own, float& pr, float& se, float& sa,
                                              uint32_t& Tmax, int& kept) {
+#ifdef OCC_DBG_BOUNDS
+    (void)OCC_BOUND(!active || (cnt >= 0 && cnt <= OCC_LIST_CAP), 24, cnt, K);
+    const int maxc = min(wave_max_i(active ? cnt : 0), OCC_LIST_CAP);
+#else
     const int maxc = wave_max_i(active ? cnt : 0);
+#endif
     uint32_t* __restrict__ h = hist + lane * kHistStride;
     // the key is component x of the 16-byte row entry: row e of this lane sits 256 dwords further on
     const uint32_t* __restrict__ keyp = reinterpret_cast<const uint32_t*>(list) + lane * 4;
@@ -843,7 +872,7 @@ __device__ __forceinline__ void topk_select4(float4* __restrict__ list, uint32_t
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int e = e0 + i;
-                kk[i] = (!done && e < cnt) ? keyp[(size_t)e * 256] : 0u;
+                kk[i] = (!done && e < cnt && OCC_BOUND(e < OCC_LIST_CAP, 21, e, cnt)) ? keyp[(size_t)e * 256] : 0u;
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -903,7 +932,7 @@ __device__ __forceinline__ void topk_select4(float4* __restrict__ list, uint32_t
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int e = e0 + i;
-            kk[i] = (active && e < cnt) ? keyp[(size_t)e * 256] : 0xFFFFFFFFu;
+            kk[i] = (active && e < cnt && OCC_BOUND(e < OCC_LIST_CAP, 22, e, cnt)) ? keyp[(size_t)e * 256] : 0xFFFFFFFFu;
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -928,7 +957,7 @@ __device__ __forceinline__ void topk_select4(float4* __restrict__ list, uint32_t
                 se += vv[i].z;
                 sa += vv[i].w;
                 tmax = max(tmax, kk[i]);
-                if (COMPACT) list[(size_t)w * 64 + lane] = vv[i];
+                if (COMPACT && OCC_BOUND(w < OCC_LIST_CAP, 23, w, cnt)) list[(size_t)w * 64 + lane] = vv[i];
                 w += 1;
             }
         }
@@ -1040,8 +1069,12 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
     // this wave's XCD (HW_REG_XCC_ID, bits 3:0); only steers WHICH queue is drained first - any value is correct
     const int my_xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;
     int qround = 0;  // queues visited so far: own XCD's first, then the others (work stealing)
+#ifdef OCC_DBG_BOUNDS
+    int wd_iters = 0;
+#endif
 
     for (;;) {
+        OCC_WATCHDOG(35, qround, 0);
         int item = -1;
         while (qround < 8) {
             const int qq = (my_xcc + qround) & 7;
@@ -1063,16 +1096,19 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
             if (offs[mid] <= item) lo = mid; else hi = mid;
         }
         const int eo = perm_to_eo(lo, mq, P.sc.n_env);
+        if (!OCC_BOUND(eo >= 0 && eo < 3 * P.sc.n_env, 1, eo, item)) continue;
         const int local = item - offs[lo];
         ciptr rect = as_const(P.ws.objrect + eo * 4);
         const int rw = rect[2] - rect[0] + 1;
         const int by = rect[1] + local / rw, bx = rect[0] + local % rw;
         const int x0b = bx * OCC_BLOCK, y0b = by * OCC_BLOCK;
+        if (x0b < 0 || y0b < 0 || x0b + OCC_BLOCK > S || y0b + OCC_BLOCK > S) continue;  // never true for a sane rect
         const int xi = x0b + px, yi = y0b + py;
         // [P3D] pixel centre in NDC, +X left, +Y up
         const float xf = -1.0f + (2.0f * (float)(S - 1 - xi) + 1.0f) / fS;
         const float yf = -1.0f + (2.0f * (float)(S - 1 - yi) + 1.0f) / fS;
         const int n = as_const(P.ws.nrec + eo)[0];
+        if (!OCC_BOUND(xi >= 0 && xi < S && yi >= 0 && yi < S && n >= 0 && n <= cap, 2, xi | (yi << 16), n)) continue;
         OCC_STAT(0, 1);              // work items
         const float* __restrict__ recs = P.ws.rec + (size_t)eo * cap * OCC_REC_STRIDE;
         const uint4* __restrict__ bbs = reinterpret_cast<const uint4*>(P.ws.rec_bbox) + (size_t)eo * cap;
@@ -1114,7 +1150,7 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
                 }
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): leave no load pending across the hot loop
             }
-            if (acc) {
+            if (acc && OCC_BOUND(count < OCC_LIST_CAP, 3, count, item)) {
 #ifndef OCC_DBG_NO_STORE  // timing experiment only
                 // one 16-byte store per candidate; 32-bit offset from the wave-uniform base
                 *reinterpret_cast<float4*>(reinterpret_cast<char*>(mylist) + (uint32_t)(count * 1024 + lane * 16)) =
@@ -1135,7 +1171,8 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
 #ifndef OCC_DBG_NO_STAGE  // timing experiment only
             for (int idx = lane; idx < nst * kParts; idx += 64) {
                 const int k = idx / kParts, part = idx - k * kParts;
-                s_stage[k * 9 + part] = reinterpret_cast<const float4*>(recs + (size_t)s_hit[k] * OCC_REC_STRIDE)[part];
+                if (OCC_BOUND(s_hit[k] >= 0 && s_hit[k] < n, 4, s_hit[k], n))
+                    s_stage[k * 9 + part] = reinterpret_cast<const float4*>(recs + (size_t)s_hit[k] * OCC_REC_STRIDE)[part];
             }
 #endif
             __syncthreads();
@@ -1147,6 +1184,7 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
             niter = 0;
 #endif
             for (int it = 0; it < niter; ++it) {
+                OCC_WATCHDOG(31, nst, n);
                 const int slot = 4 * it + g;
                 bool active = slot < nst;
                 const int sidx = active ? slot : 0;
@@ -1161,8 +1199,8 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
                 if (__ballot(flags & (FLAG_PAIR_FIRST | FLAG_PAIR_SECOND))) {
                     const bool is_first = (flags & FLAG_PAIR_FIRST) != 0, is_second = (flags & FLAG_PAIR_SECOND) != 0;
                     bool partner = false;
-                    if (is_first && j + 1 < n) partner = touches(bbs[j + 1]);
-                    if (is_second && j >= 1) partner = touches(bbs[j - 1]);
+                    if (is_first && j + 1 < n && OCC_BOUND(j >= 0, 5, j, n)) partner = touches(bbs[j + 1]);
+                    if (is_second && j >= 1 && OCC_BOUND(j < n, 6, j, n)) partner = touches(bbs[j - 1]);
                     if (is_first && partner) active = false;
                     if (__ballot(is_second && partner)) {
                         const float4* r1 = reinterpret_cast<const float4*>(recs + (size_t)(is_second && partner ? j - 1 : j) *
@@ -1237,10 +1275,13 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
         unsigned long long cmask = 0;
         auto next_chunk = [&]() -> int {
             while (!cmask) {
+#ifdef OCC_DBG_BOUNDS
+                if (++wd_iters > 4000000) { (void)OCC_BOUND(false, 34, cwin, nch); return -1; }
+#endif
                 cwin += 64;
                 if (cwin >= nch) return -1;
                 uint4 cb = kEmptyBox;
-                if (cwin + lane < nch) cb = cbx[cwin + lane];
+                if (cwin + lane < nch && OCC_BOUND(nch <= ((cap + 63) >> 6), 7, nch, cap)) cb = cbx[cwin + lane];
                 cmask = __ballot(touches(cb) && cb.z < thrB);
             }
             const int bit = __builtin_ctzll(cmask);
@@ -1249,17 +1290,19 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
         };
         int c = next_chunk();
         uint4 bb_cur = kEmptyBox;
-        if (c >= 0 && c * 64 + lane < n) bb_cur = scan[c * 64 + lane];
+        if (c >= 0 && c * 64 + lane < n && OCC_BOUND(c * 64 + lane < cap, 8, c, n)) bb_cur = scan[c * 64 + lane];
         while (c >= 0) {
+            OCC_WATCHDOG(33, c, n);
             const int cn = next_chunk();
             uint4 bb_nxt = kEmptyBox;
-            if (cn >= 0 && cn * 64 + lane < n) bb_nxt = scan[cn * 64 + lane];
+            if (cn >= 0 && cn * 64 + lane < n && OCC_BOUND(cn * 64 + lane < cap, 9, cn, n)) bb_nxt = scan[cn * 64 + lane];
             const bool hit = touches(bb_cur) && bb_cur.z < thrB;
             const unsigned long long mask = __ballot(hit);
             OCC_STAT(5, 1);  // chunk rows scanned
             unsigned long long m = mask;
             const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
             while (m) {  // a chunk may hold more hits than the staging buffer has room for
+                OCC_WATCHDOG(32, nst, n);
                 const int room = kStage - nst;
                 const int cnt = __popcll(m);
                 const int rank = __popcll(m & lt);
@@ -1637,6 +1680,158 @@ __global__ __launch_bounds__(256) void occ_commit_kernel(CommitArgs a) {
 
 
 // ------------------------------------------------------------------------------------------
+// device-side auto-reset: pairing (one block) + commit (one block group per pair)
+// ------------------------------------------------------------------------------------------
+struct PairArgs {
+    const uint8_t* done; const float* loss_all; const int* status;
+    int n_env, n_res;
+    int* rs_state; int* rs_tries; int* pairs; int* report;
+};
+
+// ordered compaction helper: exclusive prefix of flag over a 1024-thread block (16 waves)
+__device__ __forceinline__ int block_prefix_1024(bool flag, int* s_w, int tid, int& total) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const unsigned long long m = __ballot(flag);
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    __syncthreads();  // s_w reuse
+    if (lane == 0) s_w[wave] = __popcll(m);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int v = s_w[w];
+        if (w < wave) off += v;
+        tot += v;
+    }
+    total = tot;
+    return off + __popcll(m & lt);
+}
+
+__global__ __launch_bounds__(1024) void occ_pair_kernel(PairArgs a) {
+    __shared__ int s_w[16];
+    __shared__ int s_fin[512], s_ready[512];
+    __shared__ int s_any;
+    const int tid = threadIdx.x;
+    const int N = a.n_env, R = a.n_res;
+    if (tid == 0) s_any = 0;
+    // (1) age the PENDING slots: every slot was rendered by this step's launch with its current scene
+    int st = OCC_RS_EMPTY;
+    if (tid < R) {
+        st = a.rs_state[tid];
+        if (st == OCC_RS_PENDING) {
+            const int t = a.rs_tries[tid] + 1;
+            // accept, or keep the 10th try regardless (environment.py:288,327)
+            st = (a.loss_all[N + tid] > kDoneThreshold || t >= 10) ? OCC_RS_READY : OCC_RS_EMPTY;
+            a.rs_tries[tid] = t;
+        }
+        a.report[N + R + tid] = -1;
+    }
+    int nready;
+    const int rpos = block_prefix_1024(tid < R && st == OCC_RS_READY, s_w, tid, nready);
+    if (tid < R && st == OCC_RS_READY) s_ready[rpos] = tid;
+    // (2) finished envs in index order (the first 512 are kept: no more slots than that exist)
+    int nfin = 0, any = 0;
+    for (int base = 0; base < N; base += 1024) {
+        const int i = base + tid;
+        const bool f = i < N && a.done[i] != 0;
+        if (i < N) {
+            a.report[i] = f ? 1 : 0;
+            any |= a.status[i];
+        }
+        int tot;
+        const int pos = nfin + block_prefix_1024(f, s_w, tid, tot);
+        if (f && pos < 512) s_fin[pos] = i;
+        nfin += tot;
+    }
+    if (tid < R) any |= a.status[N + tid];
+    if (any) atomicOr(&s_any, 1);
+    __syncthreads();
+    // (3) pair them
+    const int npair = min(min(nfin, nready), R);
+    if (tid < npair) {
+        const int r = s_ready[tid], i = s_fin[tid];
+        a.pairs[2 + 2 * tid] = i;
+        a.pairs[3 + 2 * tid] = N + r;
+        a.report[N + R + r] = i;
+    }
+    // a READY slot that was taken goes back to EMPTY with a fresh try count
+    const bool taken = tid < R && st == OCC_RS_READY && rpos < npair;
+    if (tid < R) {
+        if (taken) {
+            st = OCC_RS_EMPTY;
+            a.rs_tries[tid] = 0;
+        }
+        a.rs_state[tid] = st;
+        a.report[N + tid] = st;
+    }
+    if (tid == 0) {
+        a.pairs[0] = npair;
+        a.report[N + 2 * R] = s_any;
+        a.report[N + 2 * R + 1] = nfin - npair;
+    }
+}
+
+struct AutoCommitArgs {
+    const int* pairs;
+    OccEnvState st;
+    float* obs_all; float* term_obs; const float* loss_all;
+    int img, n_env;
+};
+constexpr int kCommitObsBlocks = 8, kCommitAlphaBlocks = 6;
+__global__ __launch_bounds__(256) void occ_auto_commit_kernel(AutoCommitArgs a) {
+    const int k = blockIdx.x;
+    if (k >= a.pairs[0]) return;
+    const int dst = a.pairs[2 + 2 * k], src = a.pairs[3 + 2 * k];
+    const int tid = threadIdx.x, y = blockIdx.y;
+    const size_t S2 = (size_t)a.img * a.img;
+    if (y == 0) {
+        if (tid == 0) {
+            a.st.el[dst] = a.st.el[src];
+            a.st.az[dst] = a.st.az[src];
+            a.st.radius[dst] = a.st.radius[src];
+            const float l = a.loss_all[src];
+            a.st.full_reward[dst] = l;
+            a.st.object_mass[dst] = l + 1.0f;
+        }
+        if (tid < 3) {
+            a.st.campos[dst * 3 + tid] = 0.f;
+            a.st.scene_mesh[dst * 3 + tid] = a.st.scene_mesh[src * 3 + tid];
+        }
+        if (tid < 9) a.st.scene_offset[dst * 9 + tid] = a.st.scene_offset[src * 9 + tid];
+        if (tid < OCC_CAM_STRIDE) a.st.cam[(size_t)dst * OCC_CAM_STRIDE + tid] = a.st.cam[(size_t)src * OCC_CAM_STRIDE + tid];
+    } else if (y <= kCommitObsBlocks) {
+        // final observation -> term_obs[slot], reset observation -> obs[env] (same element range, same thread)
+        const float4* s4 = reinterpret_cast<const float4*>(a.obs_all + (size_t)src * 4 * S2);
+        float4* d4 = reinterpret_cast<float4*>(a.obs_all + (size_t)dst * 4 * S2);
+        float4* t4 = reinterpret_cast<float4*>(a.term_obs + (size_t)(src - a.n_env) * 4 * S2);
+        for (size_t i = (size_t)(y - 1) * 256 + tid; i < S2; i += (size_t)kCommitObsBlocks * 256) {
+            t4[i] = d4[i];
+            d4[i] = s4[i];
+        }
+    } else {
+        const float* s1 = a.st.alphas + (size_t)src * 3 * S2;
+        float* d1 = a.st.alphas + (size_t)dst * 3 * S2;
+        for (size_t i = (size_t)(y - 1 - kCommitObsBlocks) * 256 + tid; i < 3 * S2; i += (size_t)kCommitAlphaBlocks * 256)
+            d1[i] = s1[i];
+    }
+}
+
+__global__ __launch_bounds__(64) void occ_refill_kernel(const int* __restrict__ packed, int n, int n_env, int n_res,
+                                                        int* __restrict__ scene_mesh, float* __restrict__ scene_offset,
+                                                        int* __restrict__ rs_state) {
+    const int k = blockIdx.x, tid = threadIdx.x;
+    if (k >= n) return;
+    const int* row = packed + 13 * k;
+    const int slot = row[0];
+    if (slot < 0 || slot >= n_res) return;
+    const int e = n_env + slot;
+    if (tid < 3) scene_mesh[e * 3 + tid] = row[1 + tid];
+    if (tid < 9) scene_offset[e * 9 + tid] = __int_as_float(row[4 + tid]);
+    if (tid == 0) rs_state[slot] = OCC_RS_PENDING;
+}
+
+
+// ------------------------------------------------------------------------------------------
 // Operator-level replacement of PyTorch3D's _C.rasterize_meshes / _C.rasterize_meshes_backward
 // (naive path, bin_size = 0): K-buffer outputs in PyTorch3D's layout.  The fused step() above never
 // materialises these; this pair exists for callers of the rasteriser itself (SURVEY.md §8b lower surface)
@@ -1873,6 +2068,12 @@ extern "C" int occ_debug_stats(unsigned long long* out8) {
 }
 #endif
 
+#ifdef OCC_DBG_BOUNDS
+extern "C" int occ_debug_fault(int* out8) {
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(occ::g_dbg_fault), 8 * sizeof(int)) == hipSuccess ? 0 : 2;
+}
+#endif
+
 extern "C" int occ_device_cu_count(void) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -1927,6 +2128,27 @@ extern "C" int occ_camera(int mode, const float* action, float* el, float* az, c
     return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
 }
 
+// OCC_DEBUG_SYNC=1 in the environment: every launch of occ_render is announced on stderr and waited for, so that a
+// faulting kernel is the last one named (diagnostics only; serialises the stream).
+static bool dbg_sync_on() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("OCC_DEBUG_SYNC");
+        on = (e && e[0] && e[0] != '0') ? 1 : 0;
+    }
+    return on == 1;
+}
+#define OCC_DBG_SYNC(name)                                                          \
+    do {                                                                            \
+        if (dbg_sync_on()) {                                                        \
+            fprintf(stderr, "[occ] %s launched (n_env %d) ...", name, scene->n_env); \
+            fflush(stderr);                                                         \
+            const hipError_t e_ = hipStreamSynchronize(st);                         \
+            fprintf(stderr, " %s\n", e_ == hipSuccess ? "ok" : hipGetErrorString(e_)); \
+            fflush(stderr);                                                         \
+        }                                                                           \
+    } while (0)
+
 extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWorkspace* ws, const OccRenderOut* out,
                           int flags, int faces_per_pixel, void* stream) {
     if (!scene_ok(scene) || !cam || !ws || !out) return OCC_ERR_ARG;
@@ -1946,11 +2168,13 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
         hipLaunchKernelGGL(occ_setup_kernel<true>, dim3(N * 3), dim3(256), 0, st, *scene, cam, *ws);
     else
         hipLaunchKernelGGL(occ_setup_kernel<false>, dim3(N * 3), dim3(256), 0, st, *scene, cam, *ws);
+    OCC_DBG_SYNC("setup");
     if (scene->rec_cap >= kSortMin) {
         // dense objects only: front-to-back scan order (LDS sort buffer: 8192 keys = 64 KiB)
         const int sort_cap = 8192;
         hipLaunchKernelGGL(occ_sort_kernel, dim3(N * 3), dim3(256), (size_t)sort_cap * sizeof(unsigned long long), st,
                            *scene, *ws, sort_cap);
+        OCC_DBG_SYNC("sort");
     }
     if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
     RasterParams P;
@@ -1961,6 +2185,7 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
     P.K = faces_per_pixel;
     P.ntx = scene->img / OCC_TILE;
     hipLaunchKernelGGL(occ_scan_kernel, dim3(1), dim3(1024), 0, st, ws->objrect, ws->nrec, ws->offsets, N);
+    OCC_DBG_SYNC("scan");
     if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
     const dim3 grid(ws->n_slots), block(64);
     const bool prof = g_prof_on && g_prof_n < kProfMax;
@@ -1970,12 +2195,14 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
 #define OCC_LAUNCH(SOFT_, HARD_, GRAD_)                                                             \
     do {                                                                                            \
         hipLaunchKernelGGL((occ_raster_kernel<SOFT_, HARD_, GRAD_>), grid, block, 0, st, P);        \
+        OCC_DBG_SYNC("raster");                                                                     \
         if (prof) {                                                                                 \
             (void)hipEventRecord(g_prof_ev[2 * g_prof_n + 1], st);                                  \
             g_prof_nenv[g_prof_n] = N;                                                              \
             g_prof_n += 1;                                                                          \
         }                                                                                           \
         hipLaunchKernelGGL((occ_combine_kernel<SOFT_, HARD_, GRAD_>), cgrid, cblock, 0, st, P, bpe); \
+        OCC_DBG_SYNC("combine");                                                                    \
     } while (0)
     if (soft && hard && grad)
         OCC_LAUNCH(true, true, true);
@@ -2051,6 +2278,32 @@ extern "C" int occ_reset_commit(const int32_t* pairs, int n, float* el, float* a
     CommitArgs a{pairs, n, el, az, radius, campos, cam, alphas, full_reward, object_mass, scene_mesh, scene_offset,
                  obs, obs_all, loss_all, img};
     hipLaunchKernelGGL(occ_commit_kernel, dim3(n, 3), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
+}
+
+extern "C" int occ_auto_reset(const uint8_t* done, const float* loss_all, const int32_t* status, int n_env, int n_reserve,
+                              int32_t* rs_state, int32_t* rs_tries, const OccEnvState* st, float* obs_all, float* term_obs,
+                              int img, int32_t* pairs, int32_t* report, void* stream) {
+    if (!done || !loss_all || !status || n_env <= 0 || n_reserve <= 0 || n_reserve > 512 || !rs_state || !rs_tries || !st ||
+        !obs_all || !term_obs || img <= 0 || !pairs || !report)
+        return OCC_ERR_ARG;
+    if (!st->el || !st->az || !st->radius || !st->campos || !st->cam || !st->alphas || !st->full_reward || !st->object_mass ||
+        !st->scene_mesh || !st->scene_offset)
+        return OCC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    PairArgs pa{done, loss_all, status, n_env, n_reserve, rs_state, rs_tries, pairs, report};
+    hipLaunchKernelGGL(occ_pair_kernel, dim3(1), dim3(1024), 0, s, pa);
+    AutoCommitArgs ca{pairs, *st, obs_all, term_obs, loss_all, img, n_env};
+    hipLaunchKernelGGL(occ_auto_commit_kernel, dim3(n_reserve, 1 + kCommitObsBlocks + kCommitAlphaBlocks), dim3(256), 0, s, ca);
+    return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
+}
+
+extern "C" int occ_reserve_refill(const int32_t* packed, int n, int n_env, int n_reserve, int32_t* scene_mesh,
+                                  float* scene_offset, int32_t* rs_state, void* stream) {
+    if (n == 0) return OCC_OK;
+    if (!packed || n < 0 || n_env <= 0 || n_reserve <= 0 || !scene_mesh || !scene_offset || !rs_state) return OCC_ERR_ARG;
+    hipLaunchKernelGGL(occ_refill_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, packed, n, n_env, n_reserve, scene_mesh,
+                       scene_offset, rs_state);
     return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
 }
 

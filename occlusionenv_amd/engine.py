@@ -89,6 +89,17 @@ class OcclusionEngine:
         self._ws_key = None
         self._ws = None
         self._ws_tensors = None
+        self._reserve_cam_done = False
+        if self.R:
+            # device-side auto-reset state (include/occlusionenv_amd.h: occ_auto_reset)
+            i32 = dict(dtype=torch.int32, device=d)
+            self.rs_state = torch.zeros(self.R, **i32)   # OCC_RS_EMPTY
+            self.rs_tries = torch.zeros(self.R, **i32)
+            self._pairs = torch.zeros(2 + 2 * self.R, **i32)
+            self._refill_dev = torch.zeros(self.R, 13, **i32)
+            self._refill_host = [torch.zeros(self.R, 13, dtype=torch.int32).pin_memory() for _ in range(2)]
+            self._report_host = [torch.zeros(N + 2 * self.R + 2, dtype=torch.int32).pin_memory() for _ in range(2)]
+            self._flip = 0
 
     # ---- scenes ---------------------------------------------------------------------------
     def set_scene(self, env_ids, mesh_ids, offsets) -> None:
@@ -309,6 +320,59 @@ class OcclusionEngine:
         self._mesh_all[self.N:].copy_(self._rs_mesh_host, non_blocking=True)
         self._off_all[self.N:].copy_(self._rs_off_host, non_blocking=True)
 
+    def set_reserve_state(self, state, tries) -> None:
+        """Overwrite the device-side slot states (host-driven warm-up only; no step may be in flight)."""
+        self.rs_state.copy_(torch.as_tensor(np.asarray(state), dtype=torch.int32))
+        self.rs_tries.copy_(torch.as_tensor(np.asarray(tries), dtype=torch.int32))
+
+    def refill_reserve(self, slots, mesh_ids, offsets) -> None:
+        """Hand new candidate scenes to EMPTY reserve slots: one packed H2D copy + occ_reserve_refill (scatter,
+        marks the slots PENDING).  Stream-ordered: the next step's launch renders them."""
+        n = len(slots)
+        if not n:
+            return
+        m = np.asarray(mesh_ids, dtype=np.int32).reshape(n, 3)
+        if int(m.min()) < 0 or int(m.max()) >= len(self.pool):
+            raise ValueError("mesh id outside the pool")
+        off = np.ascontiguousarray(np.asarray(offsets, dtype=np.float32).reshape(n, 9))
+        sl = np.asarray(slots, dtype=np.int64)
+        if self._rs_mesh_host is None:
+            self._rs_mesh_host = torch.zeros(self.R, 3, dtype=torch.int32).pin_memory()
+            self._rs_off_host = torch.zeros(self.R, 3, 3, dtype=torch.float32).pin_memory()
+        self._rs_mesh_host.numpy()[sl] = m
+        self._rs_off_host.numpy()[sl] = off.reshape(n, 3, 3)
+        self._flip ^= 1
+        host = self._refill_host[self._flip]
+        h = host.numpy()
+        h[:n, 0] = sl
+        h[:n, 1:4] = m
+        h[:n, 4:13] = off.view(np.int32)
+        self._refill_dev[:n].copy_(host[:n], non_blocking=True)
+        nat.check(self.lib.occ_reserve_refill(_p(self._refill_dev), n, self.N, self.R, _p(self._mesh_all), _p(self._off_all),
+                                              _p(self.rs_state), self._stream()), "occ_reserve_refill")
+
+    def auto_reset(self, out) -> dict:
+        """Device-side auto-reset of the envs that finished in the step which produced ``out`` (pairing with READY
+        reserve slots + commit, occ_auto_reset) and an asynchronous copy of its report to pinned host memory.
+        Nothing here waits for the GPU; ``event.synchronize()`` before reading ``report_host``."""
+        N, R, S = self.N, self.R, self.S
+        term = torch.empty(R, 4, S, S, dtype=torch.float32, device=self.device)
+        report = torch.empty(N + 2 * R + 2, dtype=torch.int32, device=self.device)
+        st = nat.OccEnvState()
+        st.el, st.az, st.radius = self._el_all.data_ptr(), self._az_all.data_ptr(), self._rad_all.data_ptr()
+        st.campos, st.cam, st.alphas = self.camera_position.data_ptr(), self._cam_all.data_ptr(), self._alphas_all.data_ptr()
+        st.full_reward, st.object_mass = self.full_reward.data_ptr(), self.object_mass.data_ptr()
+        st.scene_mesh, st.scene_offset = self._mesh_all.data_ptr(), self._off_all.data_ptr()
+        nat.check(self.lib.occ_auto_reset(_p(out["done_u8"]), _p(out["loss_all"]), _p(self.status), N, R, _p(self.rs_state),
+                                          _p(self.rs_tries), C.byref(st), _p(out["obs_all"]), _p(term), S, _p(self._pairs),
+                                          _p(report), self._stream()), "occ_auto_reset")
+        self._rflip = getattr(self, "_rflip", 0) ^ 1
+        host = self._report_host[self._rflip]
+        host.copy_(report, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return dict(report_host=host, event=ev, term=term, report=report)
+
     def step_flags(self, done_u8, loss_all) -> torch.Tensor:
         """(N + R + 1) int32 on the device: done | reserve scene accepted | any status bit (one D2H copy later)."""
         flags = torch.empty(self.NT + 1, dtype=torch.int32, device=self.device)
@@ -370,8 +434,10 @@ class OcclusionEngine:
         st = self._stream()
         nat.check(self.lib.occ_camera(nat.CAM_STEP, _p(actions), _p(self._el_all), _p(self._az_all), _p(self._rad_all),
                                       _p(self._cam_all), _p(self.camera_position), N, st), "occ_camera")
-        nat.check(self.lib.occ_camera(nat.CAM_LOOKAT, None, _p(self._el_all[N:]), _p(self._az_all[N:]),
-                                      _p(self._rad_all[N:]), _p(self._cam_all[N:]), None, self.R, st), "occ_camera")
+        if not self._reserve_cam_done:  # reset() camera of the reserve rows: radius 4, az = el = 0, never changes
+            nat.check(self.lib.occ_camera(nat.CAM_LOOKAT, None, _p(self._el_all[N:]), _p(self._az_all[N:]),
+                                          _p(self._rad_all[N:]), _p(self._cam_all[N:]), None, self.R, st), "occ_camera")
+            self._reserve_cam_done = True
         obs = torch.empty(NT, 4, S, S, **f32)
         fs = torch.empty(NT, S, S, 4, **f32)
         loss = torch.empty(NT, **f32)
@@ -383,6 +449,10 @@ class OcclusionEngine:
             ro.grad_elaz = g.data_ptr()
             out["grad_elaz"] = g[:N]
         sc = self._scene_struct(NT, self._mesh_all, self._off_all)
+        dump = os.environ.get("OCC_DEBUG_DUMP")
+        if dump:  # diagnostics: the inputs of the launch that is about to run (host sync)
+            torch.save(dict(mesh=self._mesh_all.cpu(), off=self._off_all.cpu(), el=self._el_all.cpu(), az=self._az_all.cpu(),
+                            rad=self._rad_all.cpu(), cam=self._cam_all.cpu(), actions=actions.cpu(), N=N, NT=NT), dump)
         nat.check(self.lib.occ_render(C.byref(sc), _p(self._cam_all), C.byref(ws), C.byref(ro), flags, self.K, st),
                   "occ_render")
         out.update(obs=obs[:N], full_state=fs[:N], loss=loss[:N], cam=self._cam_all, obs_all=obs, loss_all=loss,

@@ -131,7 +131,7 @@ def test_auto_reset_from_the_speculative_reserve(ds):
     venv._reset_envs(list(range(N)), torch.zeros(N))  # reset() itself draws unseeded azimuths (SubProcVecEnv.py:233)
     venv._warm_reserve()
     eng = venv.engine
-    assert eng.R == 2 and all(venv._rs_ready)
+    assert eng.R == 2 and bool((venv._rs_state == 2).all()) and eng.rs_state.tolist() == [2, 2]
     off = eng.scene_offset[5].clone()
     off[1, 0], off[2, 0] = 50.0, -50.0  # no occlusion left -> env 5 finishes
     eng.scene_offset[5] = off
@@ -151,6 +151,46 @@ def test_auto_reset_from_the_speculative_reserve(ds):
     # the next step runs on the new scene
     obs2, r2, d2, _ = venv.step(torch.randn(N, 2, device="cuda"))
     assert torch.isfinite(r2).all()
+
+
+def test_auto_reset_deferred_report_and_dry_reserve(ds):
+    """The auto-reset runs on the device; the host reads its report at the NEXT step (or when infos are read).
+    Three envs finish at once with two reserve slots: two are reset from the reserve by the device, the third by
+    the synchronous fallback when the report is read; the emptied slots get new scenes and become READY again."""
+    from environment import OcclusionEnv
+    from SubProcVecEnv import SimpleVecEnv
+
+    np.random.seed(3)
+    N, S = 16, 64
+    venv = SimpleVecEnv([lambda: OcclusionEnv(ds, img_size=S) for _ in range(N)])
+    venv._reset_envs(list(range(N)), torch.zeros(N))
+    venv._warm_reserve()
+    eng = venv.engine
+    for i in (3, 7, 11):
+        off = eng.scene_offset[i].clone()
+        off[1, 0], off[2, 0] = 50.0, -50.0
+        eng.scene_offset[i] = off
+    old_scenes = {i: venv.envs[i]._scene for i in (3, 7, 11)}
+    obs, rewards, dones, infos = venv.step(torch.zeros(N, 2, device="cuda"))
+    assert venv._pending is not None, "report not read yet: the host ran ahead"
+    assert dones[[3, 7, 11]].all()
+    # device state already reset for the two lowest finished envs (pairing is in index order)
+    assert float(eng.camera_position[3].abs().sum()) == 0.0 and float(eng.camera_position[7].abs().sum()) == 0.0
+    assert sorted(eng.rs_state.tolist()) == [0, 0]
+    # reading infos forces the bookkeeping, incl. the fallback reset of env 11
+    for i in (3, 7, 11):
+        assert infos[i]["terminal_observation"].shape == (1, 4, S, S)
+        assert venv.envs[i]._scene is not old_scenes[i]
+        assert float(eng.object_mass[i]) == pytest.approx(float(eng.full_reward[i]) + 1.0)
+        ids, offs = venv.envs[i]._scene
+        ref = eng.evaluate_scenes([ids], [offs], 4.0, 0.0, 0.0)
+        assert torch.equal(ref["obs"][0], obs[i])
+    assert venv._pending is None and eng.rs_state.tolist() == [1, 1]  # refilled, under test
+    # a few more steps: the rejection loop advances on the device until both slots are READY again
+    for _ in range(12):
+        venv.step(torch.zeros(N, 2, device="cuda"))
+    venv._drain()
+    assert eng.rs_state.tolist() == [2, 2] and venv._rs_state.tolist() == [2, 2]
 
 
 def test_harness_gradient_ascent_and_rollout(ds):
@@ -200,6 +240,10 @@ def test_full_size_properties(ds):
     exp = (fr0 - loss) / om + torch.where(loss < 0.1, torch.tensor(5.0, device="cuda"), torch.tensor(-0.2, device="cuda"))
     assert torch.allclose(reward.detach(), exp, atol=1e-5) and torch.equal(done, loss < 0.1)
     assert torch.isfinite(a.grad).all() and float(a.grad.abs().max()) > 0
+    # block rect of every (env, object) stays inside the image (the raster kernel's work items come from it)
+    rect = eng._ws_tensors["objrect"][: 4 * 3 * N].view(-1, 4)
+    vis = eng._ws_tensors["nrec"][: 3 * N] > 0
+    assert int(rect[vis].min()) >= 0 and int(rect[vis].max()) < S // 4
     # the gradient is orthogonal to the action (reward depends on a / |a| only, environment.py:356-358)
     rad = (a.grad * a.detach()).sum(1).abs() / (a.grad.norm(dim=1) * a.detach().norm(dim=1)).clamp(min=1e-12)
     assert float(rad.max()) < 1e-3
