@@ -231,8 +231,11 @@ class SimpleVecEnv(VecEnv):
         if R:
             if not self._warm:
                 self._warm_reserve()
-            empty = self._drain(defer_refill=True)
-            obs, rewards, dones, full_state, loss, out = eng.step(actions, with_reserve=True)
+            # the report of the previous step is read as late as possible: after this step's outputs are allocated
+            # and its launch arguments are built, right before its first kernel launch
+            empty = []
+            obs, rewards, dones, full_state, loss, out = eng.step(
+                actions, with_reserve=True, pre_launch=lambda: empty.extend(self._drain(defer_refill=True)))
             # finished envs are reset ON THE DEVICE from the reserve (pairing + commit); the host reads the
             # report later (_drain).  NB out["obs_all"][:N] IS obs: the commit writes the reset observation in place
             pend = eng.auto_reset(out)

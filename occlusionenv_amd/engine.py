@@ -394,10 +394,12 @@ class OcclusionEngine:
                                             self.S, self._stream()), "occ_reset_commit")
         out["_pairs"] = pairs
 
-    def step(self, actions: torch.Tensor, env_ids=None, with_reserve: bool = False):
+    def step(self, actions: torch.Tensor, env_ids=None, with_reserve: bool = False, pre_launch=None):
         """Batched step(): returns (obs (n,4,S,S), reward (n,) [autograd-attached], done (n,) bool, full_state, loss).
         ``with_reserve`` (whole-batch steps only) also renders the reserve scenes in the same launch sequence and
-        returns a sixth item: the dict of whole-batch tensors (``obs_all``, ``loss_all`` ...)."""
+        returns a sixth item: the dict of whole-batch tensors (``obs_all``, ``loss_all`` ...).  ``pre_launch`` (with
+        the reserve only) is called after every output is allocated and every argument struct is built, right
+        before the first kernel launch: the place for a host sync that must precede this step."""
         idx = None if env_ids is None else torch.as_tensor(env_ids, dtype=torch.long, device=self.device).reshape(-1)
         n = self.N if idx is None else int(idx.numel())
         if actions.shape != (n, 2):
@@ -406,14 +408,16 @@ class OcclusionEngine:
         a = actions.detach().to(self.device, torch.float32).contiguous()
         flags = nat.RENDER_SOFT | nat.RENDER_HARD | (nat.RENDER_GRAD if need_grad else 0)
         d = self.device
-        if with_reserve and idx is None and self.R > 0:
-            out = self._render_with_reserve(a, flags)
-        else:
-            with_reserve = False
-            out = self._render(idx, nat.CAM_STEP, a, flags)
         reward = torch.empty(n, dtype=torch.float32, device=d)
         done = torch.empty(n, dtype=torch.uint8, device=d)
         grad_action = torch.empty(n, 2, dtype=torch.float32, device=d) if need_grad else None
+        if with_reserve and idx is None and self.R > 0:
+            out = self._render_with_reserve(a, flags, pre_launch)
+        else:
+            with_reserve = False
+            if pre_launch is not None:
+                pre_launch()
+            out = self._render(idx, nat.CAM_STEP, a, flags)
         fr = self.full_reward if idx is None else self.full_reward[idx]
         om = self.object_mass if idx is None else self.object_mass[idx]
         nat.check(self.lib.occ_step_finish(_p(out["loss"]), _p(out.get("grad_elaz")), _p(out["cam"]), _p(fr), _p(om),
@@ -426,18 +430,12 @@ class OcclusionEngine:
         out["done_u8"] = done
         return res + (out,) if with_reserve else res
 
-    def _render_with_reserve(self, actions, flags):
+    def _render_with_reserve(self, actions, flags, pre_launch=None):
         """One launch sequence over N stepping envs (OCC_CAM_STEP) + R reserve scenes (OCC_CAM_LOOKAT)."""
         ws = self._ensure_workspace()
         d, S, N, NT = self.device, self.S, self.N, self.NT
         f32 = dict(dtype=torch.float32, device=d)
         st = self._stream()
-        nat.check(self.lib.occ_camera(nat.CAM_STEP, _p(actions), _p(self._el_all), _p(self._az_all), _p(self._rad_all),
-                                      _p(self._cam_all), _p(self.camera_position), N, st), "occ_camera")
-        if not self._reserve_cam_done:  # reset() camera of the reserve rows: radius 4, az = el = 0, never changes
-            nat.check(self.lib.occ_camera(nat.CAM_LOOKAT, None, _p(self._el_all[N:]), _p(self._az_all[N:]),
-                                          _p(self._rad_all[N:]), _p(self._cam_all[N:]), None, self.R, st), "occ_camera")
-            self._reserve_cam_done = True
         obs = torch.empty(NT, 4, S, S, **f32)
         fs = torch.empty(NT, S, S, 4, **f32)
         loss = torch.empty(NT, **f32)
@@ -449,6 +447,19 @@ class OcclusionEngine:
             ro.grad_elaz = g.data_ptr()
             out["grad_elaz"] = g[:N]
         sc = self._scene_struct(NT, self._mesh_all, self._off_all)
+        ver = self.pool.version
+        cam_args = (nat.CAM_STEP, _p(actions), _p(self._el_all), _p(self._az_all), _p(self._rad_all), _p(self._cam_all),
+                    _p(self.camera_position), N, st)
+        if pre_launch is not None:
+            pre_launch()
+            if self.pool.version != ver:  # a fallback reset inside pre_launch added meshes: the pool was re-packed
+                ws = self._ensure_workspace()
+                sc = self._scene_struct(NT, self._mesh_all, self._off_all)
+        nat.check(self.lib.occ_camera(*cam_args), "occ_camera")
+        if not self._reserve_cam_done:  # reset() camera of the reserve rows: radius 4, az = el = 0, never changes
+            nat.check(self.lib.occ_camera(nat.CAM_LOOKAT, None, _p(self._el_all[N:]), _p(self._az_all[N:]),
+                                          _p(self._rad_all[N:]), _p(self._cam_all[N:]), None, self.R, st), "occ_camera")
+            self._reserve_cam_done = True
         dump = os.environ.get("OCC_DEBUG_DUMP")
         if dump:  # diagnostics: the inputs of the launch that is about to run (host sync)
             torch.save(dict(mesh=self._mesh_all.cpu(), off=self._off_all.cpu(), el=self._el_all.cpu(), az=self._az_all.cpu(),

@@ -193,6 +193,35 @@ def test_auto_reset_deferred_report_and_dry_reserve(ds):
     assert eng.rs_state.tolist() == [2, 2] and venv._rs_state.tolist() == [2, 2]
 
 
+def test_soak_many_steps_with_auto_reset(ds):
+    """A long batched rollout (512 envs x 120 steps, random actions): auto-resets from the reserve keep flowing,
+    every work-item rect stays inside the image, no status bit is raised, outputs stay finite."""
+    from environment import OcclusionEnv
+    from SubProcVecEnv import SimpleVecEnv
+
+    N, S = 512, 128
+    venv = SimpleVecEnv([lambda: OcclusionEnv(ds, img_size=S) for _ in range(N)])
+    az0 = (torch.rand(N, generator=torch.Generator().manual_seed(1)) * 2 - 1) * 0.6
+    venv._reset_envs(list(range(N)), az0)
+    venv._warm_reserve()
+    eng = venv.engine
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    n_done = 0
+    for step in range(120):
+        a = torch.randn(N, 2, device="cuda", generator=gen, requires_grad=True)
+        obs, rewards, dones, infos = venv.step(a)
+        rewards.sum().backward()
+        if step % 10 == 9:
+            n_done += int(dones.sum())
+            assert torch.isfinite(rewards).all() and torch.isfinite(a.grad).all() and torch.isfinite(obs).all()
+            rect = eng._ws_tensors["objrect"][: 12 * eng.NT].view(-1, 4)
+            vis = eng._ws_tensors["nrec"][: 3 * eng.NT] > 0
+            assert int(rect[vis].min()) >= 0 and int(rect[vis].max()) < S // 4
+    venv._drain()
+    eng.check_status()
+    assert n_done > 0, "some envs must have finished and been reset along the way"
+
+
 def test_harness_gradient_ascent_and_rollout(ds):
     """H1 counterparts: demo.py's gradient-ascent loop reduces the occlusion; a T-step batched rollout yields
     well-formed 261-float records and finite action gradients."""
