@@ -1,0 +1,163 @@
+"""Batched counterpart of the reference's PPO learner for the vectorised env.
+
+The reference (/root/reference/PPO.py) drives ONE env: ``select_action`` stores the frozen encoder's 256-d pooled
+feature, the action and its log-probability per step (PPO.py:152-164); ``update`` turns the reward list into
+Monte-Carlo returns that restart at terminals (PPO.py:178-188), normalises them, and runs K epochs of the clipped
+surrogate over the ACTION and VALUE heads only (optimizer over ``action_head`` / ``value_head``, PPO.py:113-116;
+``FullNetwork.act`` detaches the features, model.py:168-171).
+
+Here the buffer is the (T, N, 261) rollout-record tensor of ``rollout.pack_records`` (features | action | logprob |
+reward | done), every env is its own trajectory, and the update is one batched pass over T*N samples.  With several
+GPUs every rank all-gathers the records (``rollout.all_gather_records``) and runs the SAME update on the same
+data with the same seed: the learner is replicated, no gradient collective is needed (the heads are 771 floats).
+The encoder itself is out of scope: ``rollout.pooled_features`` stands in for it.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import rollout
+
+LOG_2PI = math.log(2.0 * math.pi)
+
+
+def mc_returns(rewards: torch.Tensor, dones: torch.Tensor, gamma: float) -> torch.Tensor:
+    """Monte-Carlo returns per env, restarting at terminals (PPO.py:178-185, one reversed scan per env).
+    rewards, dones: (T, N) -> (T, N)."""
+    T = rewards.shape[0]
+    out = torch.empty_like(rewards)
+    running = torch.zeros_like(rewards[0])
+    not_done = 1.0 - dones.to(rewards.dtype)
+    for t in range(T - 1, -1, -1):
+        running = rewards[t] + gamma * running * not_done[t]
+        out[t] = running
+    return out
+
+
+class ActorCriticHeads(nn.Module):
+    """``FullNetwork.action_head`` / ``value_head`` (model.py:153-154,168-171) on 256-d features, with the fixed
+    diagonal Gaussian of ``ActorCritic`` (PPO.py:43-45,62-80,82-104)."""
+
+    def __init__(self, feat_dim: int = 256, action_dim: int = 2, action_std_init: float = 0.6):
+        super().__init__()
+        self.action_dim = action_dim
+        self.action_head = nn.Linear(feat_dim, action_dim)
+        self.value_head = nn.Linear(feat_dim, 1)
+        self.register_buffer("action_var", torch.full((action_dim,), action_std_init * action_std_init))
+
+    def set_action_std(self, new_action_std: float) -> None:
+        self.action_var.fill_(new_action_std * new_action_std)
+
+    def _logprob_entropy(self, mean, action):
+        # MultivariateNormal(mean, diag(var)): log N and entropy in closed form
+        var = self.action_var
+        logdet = torch.log(var).sum()
+        lp = -0.5 * (((action - mean) ** 2) / var).sum(-1) - 0.5 * (self.action_dim * LOG_2PI + logdet)
+        ent = 0.5 * (self.action_dim * (1.0 + LOG_2PI) + logdet)
+        return lp, ent.expand(mean.shape[:-1])
+
+    @torch.no_grad()
+    def act(self, features: torch.Tensor, generator: Optional[torch.Generator] = None):
+        mean = self.action_head(features)
+        eps = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
+        action = mean + eps * self.action_var.sqrt()
+        lp, _ = self._logprob_entropy(mean, action)
+        return action, lp
+
+    def evaluate(self, features: torch.Tensor, action: torch.Tensor):
+        feats = features.detach()
+        mean = self.action_head(feats)
+        value = self.value_head(feats).squeeze(-1)
+        lp, ent = self._logprob_entropy(mean, action)
+        return lp, value, ent
+
+
+class BatchedPPO:
+    """PPO (PPO.py:107-223) over batched rollouts.  Hyper-parameters default to trainRL.py:42-56."""
+
+    def __init__(self, lr_actor: float = 3e-4, lr_critic: float = 1e-3, gamma: float = 0.99, K_epochs: int = 80,
+                 eps_clip: float = 0.2, action_std_init: float = 0.6, device=None, seed: Optional[int] = None):
+        self.gamma, self.eps_clip, self.K_epochs = gamma, eps_clip, K_epochs
+        self.action_std = action_std_init
+        if seed is not None:
+            torch.manual_seed(seed)
+        self.policy = ActorCriticHeads(action_std_init=action_std_init).to(device)
+        self.policy_old = ActorCriticHeads(action_std_init=action_std_init).to(device)
+        self.policy_old.load_state_dict(self.policy.state_dict())
+        self.optimizer = torch.optim.Adam([
+            {"params": self.policy.action_head.parameters(), "lr": lr_actor},
+            {"params": self.policy.value_head.parameters(), "lr": lr_critic},
+        ])
+        self.records = []  # list of (N_total, 261) tensors, one per step
+
+    # ---- acting (PPO.py:152-164) ------------------------------------------------------------
+    def select_action(self, obs: torch.Tensor, generator: Optional[torch.Generator] = None):
+        """obs (N,4,S,S) -> (features, action, logprob) from the OLD policy."""
+        feats = rollout.pooled_features(obs)
+        action, logprob = self.policy_old.act(feats, generator)
+        return feats, action, logprob
+
+    def store(self, record: torch.Tensor) -> None:
+        self.records.append(record)
+
+    def set_action_std(self, new_action_std: float) -> None:
+        self.action_std = new_action_std
+        self.policy.set_action_std(new_action_std)
+        self.policy_old.set_action_std(new_action_std)
+
+    def decay_action_std(self, rate: float, min_std: float) -> None:
+        self.set_action_std(max(round(self.action_std - rate, 4), min_std))  # PPO.py:136-149
+
+    # ---- learning (PPO.py:176-217) ----------------------------------------------------------
+    def update(self) -> dict:
+        rec = torch.stack(self.records)  # (T, N, 261)
+        feats, actions = rec[..., :256], rec[..., 256:258]
+        old_lp, rewards, dones = rec[..., 258], rec[..., 259], rec[..., 260]
+        returns = mc_returns(rewards, dones, self.gamma)
+        returns = (returns - returns.mean()) / (returns.std() + 1e-7)
+        feats, actions = feats.reshape(-1, 256), actions.reshape(-1, 2)
+        old_lp, returns = old_lp.reshape(-1), returns.reshape(-1)
+        first = last = None
+        for _ in range(self.K_epochs):
+            lp, value, ent = self.policy.evaluate(feats, actions)
+            ratios = torch.exp(lp - old_lp)
+            adv = returns - value.detach()
+            surr1 = ratios * adv
+            surr2 = torch.clamp(ratios, 1 - self.eps_clip, 1 + self.eps_clip) * adv
+            loss = (-torch.min(surr1, surr2) + 0.5 * torch.mean((value - returns) ** 2) - 0.01 * ent).mean()
+            self.optimizer.zero_grad()
+            loss.backward()
+            self.optimizer.step()
+            last = float(loss.detach())
+            first = last if first is None else first
+        self.policy_old.load_state_dict(self.policy.state_dict())
+        self.records = []
+        return dict(loss_first=first, loss_last=last, samples=int(feats.shape[0]))
+
+
+def train_rollouts(venv, agent: BatchedPPO, n_updates: int = 1, T: int = 50, with_action_grad: bool = False,
+                   generator: Optional[torch.Generator] = None) -> list:
+    """trainRL.py:189-229, batched: T vectorised steps (auto-reset inside the env) -> one PPO update; repeated.
+    Returns the per-update stats (mean reward, loss before/after)."""
+    obs = venv.reset()[:, 0]
+    stats = []
+    for _ in range(n_updates):
+        rew_sum = torch.zeros((), device=obs.device)
+        for _t in range(T):
+            feats, action, logprob = agent.select_action(obs, generator)
+            action = action.detach().requires_grad_(with_action_grad)
+            obs, rewards, dones, _infos = venv.step(action)
+            if with_action_grad:
+                rewards.sum().backward()
+            rec = rollout.pack_records(obs, action, logprob, rewards, dones)
+            rec[:, :256] = feats  # the state that produced the action (PPO.py:158), not the next one
+            agent.store(rollout.all_gather_records(rec))
+            rew_sum = rew_sum + rewards.detach().mean()
+        st = agent.update()
+        st["mean_reward"] = float(rew_sum) / T
+        stats.append(st)
+    return stats

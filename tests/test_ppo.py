@@ -1,0 +1,70 @@
+"""Batched PPO learner counterpart against the reference's algorithm restated inline
+(/root/reference/PPO.py:62-104,176-217)."""
+import torch
+from torch.distributions import MultivariateNormal
+
+from occlusionenv_amd import ppo, rollout
+
+
+def _returns_reference_style(rewards, terminals, gamma):
+    """PPO.py:178-185 for ONE env: reversed scan, restart at terminals."""
+    out, running = [], 0.0
+    for r, d in zip(reversed(rewards), reversed(terminals)):
+        if d:
+            running = 0.0
+        running = r + gamma * running
+        out.insert(0, running)
+    return out
+
+
+def test_mc_returns_match_per_env_scan():
+    g = torch.Generator().manual_seed(0)
+    T, N = 17, 5
+    rewards = torch.randn(T, N, generator=g)
+    dones = torch.rand(T, N, generator=g) < 0.2
+    got = ppo.mc_returns(rewards, dones, 0.99)
+    for n in range(N):
+        exp = _returns_reference_style(rewards[:, n].tolist(), dones[:, n].tolist(), 0.99)
+        assert torch.allclose(got[:, n], torch.tensor(exp), atol=1e-5)
+
+
+def test_logprob_and_entropy_equal_multivariate_normal():
+    torch.manual_seed(1)
+    heads = ppo.ActorCriticHeads(action_std_init=0.6)
+    feats = torch.randn(7, 256)
+    actions = torch.randn(7, 2)
+    lp, value, ent = heads.evaluate(feats, actions)
+    mean = heads.action_head(feats)
+    dist = MultivariateNormal(mean, torch.diag_embed(heads.action_var.expand_as(mean)))  # PPO.py:87-90
+    assert torch.allclose(lp, dist.log_prob(actions), atol=1e-5)
+    assert torch.allclose(ent, dist.entropy(), atol=1e-5)
+    assert value.shape == (7,)
+    a, alp = heads.act(feats)
+    assert torch.allclose(alp, dist.log_prob(a), atol=1e-5)
+    heads.set_action_std(0.3)
+    assert torch.allclose(heads.action_var, torch.full((2,), 0.09))
+
+
+def test_update_trains_heads_and_syncs_old_policy():
+    agent = ppo.BatchedPPO(K_epochs=20, seed=0)
+    g = torch.Generator().manual_seed(2)
+    T, N = 12, 16
+    w_true = torch.randn(256, generator=g) * 0.1
+    for _ in range(T):
+        obs = torch.rand(N, 4, 32, 32, generator=g)
+        feats, action, logprob = agent.select_action(obs)
+        assert feats.shape == (N, 256) and action.shape == (N, 2) and logprob.shape == (N,)
+        rewards = feats @ w_true + 0.1 * action[:, 0]
+        dones = torch.rand(N, generator=g) < 0.1
+        rec = rollout.pack_records(obs, action, logprob, rewards, dones)
+        agent.store(rec)
+    before = {k: v.clone() for k, v in agent.policy.state_dict().items()}
+    st = agent.update()
+    assert st["samples"] == T * N and st["loss_last"] < st["loss_first"]
+    after = agent.policy.state_dict()
+    assert any(not torch.equal(before[k], after[k]) for k in before if "head" in k)
+    for k, v in agent.policy_old.state_dict().items():
+        assert torch.equal(v, after[k])
+    assert agent.records == []
+    agent.decay_action_std(0.05, 0.1)
+    assert abs(agent.action_std - 0.55) < 1e-6 and torch.allclose(agent.policy_old.action_var, torch.full((2,), 0.55 ** 2))
