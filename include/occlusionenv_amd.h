@@ -52,7 +52,7 @@ extern "C" {
 
 /* layout constants shared with the host */
 #define OCC_CAM_STRIDE 48  /* floats per env in the camera buffer */
-#define OCC_REC_STRIDE 36  /* floats per projected-face record (nine 16-byte parts) */
+#define OCC_REC_STRIDE 32  /* floats per projected-face record (eight 16-byte parts = one 128-byte line) */
 #define OCC_TILE 8         /* image sides must be a multiple of this */
 #define OCC_BLOCK 4        /* pixels per block side: one wave64 work item = 4x4 pixels x 4 face slots */
 #ifndef OCC_LIST_CAP

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("OCC_HIP_LIB") or os.path.join(_HERE, "libocc_hip.so")
 # layout constants (must match include/occlusionenv_amd.h)
 ABI_VERSION = 1
 CAM_STRIDE = 48
-REC_STRIDE = 36
+REC_STRIDE = 32
 TILE = 8
 LIST_CAP = 512
 MAX_K = 128

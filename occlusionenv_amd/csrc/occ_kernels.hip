@@ -314,12 +314,11 @@ __device__ __forceinline__ void write_record(float* __restrict__ r, uint4* __res
     r4[3] = make_float4(fmin3(x0, x1, x2) - kSqrtBlur, fmax3(x0, x1, x2) + kSqrtBlur, fmin3(y0, y1, y2) - kSqrtBlur,
                         fmax3(y0, y1, y2) + kSqrtBlur);
     r4[4] = make_float4(l01 <= kEpsilon ? -1.0f : 1.0f / l01, l02 <= kEpsilon ? -1.0f : 1.0f / l02,
-                        l12 <= kEpsilon ? -1.0f : 1.0f / l12, 1.0f / (l01 + kEpsilon));
-    r4[5] = make_float4(1.0f / (l02 + kEpsilon), 1.0f / (l12 + kEpsilon), 0.f, 0.f);
+                        l12 <= kEpsilon ? -1.0f : 1.0f / l12, 0.f);
     if (GRAD) {
-        r4[6] = make_float4(t.v[0].t[0], t.v[0].t[1], t.v[0].t[2], t.v[0].t[3]);
-        r4[7] = make_float4(t.v[1].t[0], t.v[1].t[1], t.v[1].t[2], t.v[1].t[3]);
-        r4[8] = make_float4(t.v[2].t[0], t.v[2].t[1], t.v[2].t[2], t.v[2].t[3]);
+        r4[5] = make_float4(t.v[0].t[0], t.v[0].t[1], t.v[0].t[2], t.v[0].t[3]);
+        r4[6] = make_float4(t.v[1].t[0], t.v[1].t[1], t.v[1].t[2], t.v[1].t[3]);
+        r4[7] = make_float4(t.v[2].t[0], t.v[2].t[1], t.v[2].t[2], t.v[2].t[3]);
     }
     *bb = t.bbox;
     // scan row in face order (occ_sort_kernel re-orders dense objects): (pixel bbox, nearest depth key, record index)
@@ -490,7 +489,7 @@ template <bool GRAD>
 __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const float* __restrict__ cam, OccWorkspace ws) {
     __shared__ int s_wcnt[2][4];  // double-buffered: one barrier per 256-face round
     __shared__ int s_rect[4];
-    __shared__ float4 s_rec[4 * 64 * 9];  // per wave: the records of one round, staged for coalesced stores
+    __shared__ float4 s_rec[4 * 64 * kRecParts];  // per wave: the records of one round, staged for coalesced stores
     const int eo = blockIdx.x;  // env*3 + object
     const int env = eo / 3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -591,17 +590,17 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
                             PVert pk;
                             view_from_world<true>(C, w0, q);
                             pk = project<true>(q);
-                            reinterpret_cast<float4*>(r)[6] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
+                            reinterpret_cast<float4*>(r)[5] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
                             view_from_world<true>(C, w1, q);
                             pk = project<true>(q);
-                            reinterpret_cast<float4*>(r)[7] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
+                            reinterpret_cast<float4*>(r)[6] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
                             view_from_world<true>(C, w2, q);
                             pk = project<true>(q);
-                            reinterpret_cast<float4*>(r)[8] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
+                            reinterpret_cast<float4*>(r)[7] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
                         }
                     };
                     if (staged) {
-                        emit(reinterpret_cast<float*>(&s_rec[(wave * 64 + pre) * 9]));
+                        emit(reinterpret_cast<float*>(&s_rec[(wave * 64 + pre) * kRecParts]));
                     } else {
                         emit(rec + (size_t)pos * OCC_REC_STRIDE);
                     }
@@ -628,12 +627,12 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
         if (staged) {  // wave-uniform
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            constexpr int kP = GRAD ? 9 : 6;  // parts this variant writes
+            constexpr int kP = GRAD ? kRecParts : 5;  // parts this variant writes
             float4* __restrict__ dst = reinterpret_cast<float4*>(rec + (size_t)wstart * OCC_REC_STRIDE);
-            const float4* src = &s_rec[wave * 64 * 9];
+            const float4* src = &s_rec[wave * 64 * kRecParts];
             for (int i = lane; i < nw * kP; i += 64) {
                 const int rj = i / kP, part = i - rj * kP;
-                dst[rj * 9 + part] = src[rj * 9 + part];
+                dst[rj * kRecParts + part] = src[rj * kRecParts + part];
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -692,15 +691,15 @@ struct Cand {
 // RasterizeMeshesBackward (A.5) pushed forward along the two vertex tangents.
 // One staged record pulled out of LDS with 16-byte broadcast reads (every lane reads the same address).
 // Slot map as in occ_constants.h:
-//   a = x0 y0 z0 x1 | b = y1 z1 x2 y2 | c = z2 id flags inv_area | d = bbox | e = il01 il02 il12 ile01 |
-//   f = ile02 ile12 - - | g, h, i = tangents of v0, v1, v2 (dx/del dy/del dx/daz dy/daz)
+//   a = x0 y0 z0 x1 | b = y1 z1 x2 y2 | c = z2 id flags inv_area | d = bbox | e = il01 il02 il12 - |
+//   g, h, i = tangents of v0, v1, v2 (dx/del dy/del dx/daz dy/daz)      -- 8 parts = 128 bytes = one cache line
 // The nine float4 parts travel as SSA values (by value, never through a struct in memory: a select between two
 // loads of one stack object gets folded into a dynamically indexed load, which pins the object in scratch).
-#define OCC_REC_PARAMS float4 ra, float4 rb, float4 rc, float4 rd, float4 re, float4 rf, float4 rg, float4 rh, float4 ri
+#define OCC_REC_PARAMS float4 ra, float4 rb, float4 rc, float4 rd, float4 re, float4 rg, float4 rh, float4 ri
 #define OCC_REC_LOAD(src, PARTS)                                                                   \
     (src)[0], (src)[1], (src)[2], (src)[3], ((PARTS) > 4 ? (src)[4] : make_float4(0, 0, 0, 0)),      \
-        ((PARTS) > 4 ? (src)[5] : make_float4(0, 0, 0, 0)), ((PARTS) > 6 ? (src)[6] : make_float4(0, 0, 0, 0)), \
-        ((PARTS) > 6 ? (src)[7] : make_float4(0, 0, 0, 0)), ((PARTS) > 6 ? (src)[8] : make_float4(0, 0, 0, 0))
+        ((PARTS) > 5 ? (src)[5] : make_float4(0, 0, 0, 0)), ((PARTS) > 5 ? (src)[6] : make_float4(0, 0, 0, 0)), \
+        ((PARTS) > 5 ? (src)[7] : make_float4(0, 0, 0, 0))
 
 // Evaluate one projected face at this lane's pixel centre.
 template <bool SOFT, bool GRAD>
@@ -772,7 +771,9 @@ __device__ __forceinline__ void eval_face(OCC_REC_PARAMS, float xf, float yf, Ca
         const float bax = s01 ? ex01 : (s02 ? ex02 : ex12);
         const float bay = s01 ? ey01 : (s02 ? ey02 : ey12);
         const float dotv = s01 ? dot01 : (s02 ? dot02 : dot12);
-        const float ile = s01 ? re.w : (s02 ? rf.x : rf.y);
+        // 1 / (|b-a|^2 + eps) from the stored 1 / |b-a|^2 (a degenerate edge is flagged -1: its |b-a|^2 <= eps)
+        const float il = s01 ? il01 : (s02 ? il02 : il12);
+        const float ile = il < 0.f ? 0.5f / kEpsilon : il * frcp(1.0f + kEpsilon * il);
         const float pax = s12 ? dx1 : dx0, pay = s12 ? dy1 : dy0;
         const float tb = clamp01(dotv * ile);
         const float gx = 2.0f * (tb * bax - pax), gy = 2.0f * (tb * bay - pay);  // 2 (proj - p)
@@ -1060,9 +1061,9 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
     __shared__ uint32_t s_hist[64 * kHistStride];
     // records of the faces that touch this block, gathered over as many 64-face chunks as fit, staged by
     // cooperative 16-B loads (one memory round trip per <= 64 staged faces)
-    constexpr int kParts = GRAD ? 9 : (SOFT ? 6 : 4);  // float4 parts of a record that this variant reads
-    constexpr int kStage = 32;  // 32 x 144 B: keeps the wave at ~9 KiB of LDS -> 16 waves per CU
-    __shared__ float4 s_stage[kStage * 9];
+    constexpr int kParts = GRAD ? kRecParts : (SOFT ? 5 : 4);  // float4 parts of a record that this variant reads
+    constexpr int kStage = 56;  // 56 x 128 B = 7 KiB: the wave stays below 10 KiB of LDS -> 16 waves per CU
+    __shared__ float4 s_stage[kStage * kRecParts];
     __shared__ int s_hit[kStage];  // record index of every staged face
     ciptr offs = as_const(P.ws.offsets);
     const int mq = xcd_slots(P.sc.n_env), MP = 8 * mq;
@@ -1172,7 +1173,7 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
             for (int idx = lane; idx < nst * kParts; idx += 64) {
                 const int k = idx / kParts, part = idx - k * kParts;
                 if (OCC_BOUND(s_hit[k] >= 0 && s_hit[k] < n, 4, s_hit[k], n))
-                    s_stage[k * 9 + part] = reinterpret_cast<const float4*>(recs + (size_t)s_hit[k] * OCC_REC_STRIDE)[part];
+                    s_stage[k * kRecParts + part] = reinterpret_cast<const float4*>(recs + (size_t)s_hit[k] * OCC_REC_STRIDE)[part];
             }
 #endif
             __syncthreads();
@@ -1189,7 +1190,7 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
                 bool active = slot < nst;
                 const int sidx = active ? slot : 0;
                 const int j = s_hit[sidx];
-                const float4* rs = &s_stage[sidx * 9];
+                const float4* rs = &s_stage[sidx * kRecParts];
                 Cand c1;
                 eval_face<SOFT, GRAD>(OCC_REC_LOAD(rs, kParts), xf, yf, c1);
                 const int flags = active ? __float_as_int(rs[2].z) : 0;
