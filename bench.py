@@ -187,7 +187,8 @@ def main():
             except Exception:  # noqa: BLE001
                 traffic = None
         out = {
-            "metric": "env steps/sec (batched renders) @128x128, 3 ShapeNet-size (~5k-face) meshes per env",
+            # BASELINE.json's metric is quoted at 128x128 (the default --img); other sizes say so
+            "metric": f"env steps/sec (batched renders) @{args.img}x{args.img}, 3 ShapeNet-size (~5k-face) meshes per env",
             "value": value,
             "unit": "env-steps/s",
             "n_gpus": world,

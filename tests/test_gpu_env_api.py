@@ -193,6 +193,33 @@ def test_auto_reset_deferred_report_and_dry_reserve(ds):
     assert eng.rs_state.tolist() == [2, 2] and venv._rs_state.tolist() == [2, 2]
 
 
+def test_z_clipped_batch_properties():
+    """Cameras inside the scenes (radius 0.8 .. 1.6): many faces cross z = 0.5 (clip cases 3 and 4, split quads).
+    No oracle at this size: status clean, rects in range, alphas in [0,1], finite loss and gradients."""
+    from tests.parity_utils import make_case
+    from occlusionenv_amd.engine import OcclusionEngine
+
+    N, S = 256, 128
+    case = make_case(N, 21, "mixed")
+    eng = OcclusionEngine(case["pool"], N, S)
+    eng.set_scene(list(range(N)), case["mesh_ids"], case["offsets"])
+    radius = torch.linspace(0.8, 1.6, N)
+    eng.reset_render(None, radius, case["az"] * 3.0, 0.0)
+    for _ in range(3):
+        a = torch.randn(N, 2, device="cuda", requires_grad=True)
+        obs, reward, done, fs, loss = eng.step(a)
+        reward.sum().backward()
+        eng.check_status()
+        assert torch.isfinite(loss).all() and torch.isfinite(a.grad).all() and torch.isfinite(obs).all()
+        al = eng.alphas
+        assert float(al.min()) >= 0.0 and float(al.max()) <= 1.0
+        rect = eng._ws_tensors["objrect"][: 12 * N].view(-1, 4)
+        vis = eng._ws_tensors["nrec"][: 3 * N] > 0
+        assert int(rect[vis].min()) >= 0 and int(rect[vis].max()) < S // 4
+        fg = obs[:, 3] != -1.0
+        assert float(obs[:, 3][fg].min()) >= 0.5 - 1e-4  # nothing in front of the clip plane is ever drawn
+
+
 def test_soak_many_steps_with_auto_reset(ds):
     """A long batched rollout (512 envs x 120 steps, random actions): auto-resets from the reserve keep flowing,
     every work-item rect stays inside the image, no status bit is raised, outputs stay finite."""
