@@ -926,17 +926,18 @@ __device__ __forceinline__ void topk_select4(float4* __restrict__ list, uint32_t
     se = 0.f;
     sa = 0.f;
     uint32_t tmax = 0;
-    for (int e0 = 0; e0 < maxc; e0 += 8) {
-        uint32_t kk[8];
-        bool inc[8];
-        float4 vv[8];
+    // (payload sweep: 4 rows in flight - 8 would set the kernel's register peak and cost a wave per SIMD)
+    for (int e0 = 0; e0 < maxc; e0 += 4) {
+        uint32_t kk[4];
+        bool inc[4];
+        float4 vv[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const int e = e0 + i;
             kk[i] = (active && e < cnt && OCC_BOUND(e < OCC_LIST_CAP, 22, e, cnt)) ? keyp[(size_t)e * 256] : 0xFFFFFFFFu;
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const int e = e0 + i;
             const uint32_t k = kk[i];
             bool in_ = false;
@@ -952,7 +953,7 @@ __device__ __forceinline__ void topk_select4(float4* __restrict__ list, uint32_t
             if (in_) vv[i] = list[(size_t)e * 64 + lane];
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4; ++i) {
             if (inc[i]) {
                 pr *= vv[i].y;
                 se += vv[i].z;
@@ -1045,7 +1046,7 @@ __global__ __launch_bounds__(1024) void occ_scan_kernel(const int* __restrict__ 
 // counts, products, tangent sums and the nearest hard face are folded across the four lanes at the end of the
 // item, and the exact top-K selection works on the four lists jointly (topk_select4).
 #ifndef OCC_RASTER_WAVES_PER_SIMD
-#define OCC_RASTER_WAVES_PER_SIMD 4
+#define OCC_RASTER_WAVES_PER_SIMD 5
 #endif
 template <bool SOFT, bool HARD, bool GRAD>
 __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kernel(RasterParams P) {
@@ -1062,7 +1063,7 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
     // records of the faces that touch this block, gathered over as many 64-face chunks as fit, staged by
     // cooperative 16-B loads (one memory round trip per <= 64 staged faces)
     constexpr int kParts = GRAD ? kRecParts : (SOFT ? 5 : 4);  // float4 parts of a record that this variant reads
-    constexpr int kStage = 56;  // 56 x 128 B = 7 KiB: the wave stays below 10 KiB of LDS -> 16 waves per CU
+    constexpr int kStage = 40;  // 40 x 128 B = 5 KiB: the wave stays below 8 KiB of LDS -> 20 waves per CU
     __shared__ float4 s_stage[kStage * kRecParts];
     __shared__ int s_hit[kStage];  // record index of every staged face
     ciptr offs = as_const(P.ws.offsets);

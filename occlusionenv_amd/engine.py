@@ -59,7 +59,7 @@ class OcclusionEngine:
         self.N = int(n_env)
         self.S = int(img_size)
         self.K = int(faces_per_pixel)
-        self.waves_per_cu = int(waves_per_cu or os.environ.get("OCC_WAVES_PER_CU", 16))
+        self.waves_per_cu = int(waves_per_cu or os.environ.get("OCC_WAVES_PER_CU", 20))
         d = self.device
         f32 = dict(dtype=torch.float32, device=d)
         N = self.N

@@ -102,7 +102,9 @@ def test_auto_reset_on_done(ds):
     np.random.seed(1)
     N, S = 4, 64
     venv = SimpleVecEnv([lambda: OcclusionEnv(ds, img_size=S) for _ in range(N)])
-    venv.reset()
+    # reset() itself draws unseeded azimuths in +-40 rad (SubProcVecEnv.py:233): a camera on the x axis would see
+    # the objects moved below lined up behind object 1 - fix the views instead
+    venv._reset_envs(list(range(N)), torch.zeros(N))
     eng = venv.engine
     # push env 2's objects far apart: no occlusion -> loss < 0.1 -> done -> auto reset
     off = eng.scene_offset[2].clone()
