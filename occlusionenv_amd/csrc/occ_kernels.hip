@@ -297,9 +297,43 @@ __device__ __forceinline__ bool finish_tri(Tri& t, int S) {
     return vis;
 }
 
+// [P3D] HardFlatShader terms of ONE face: flat shading uses the face normal and the face centre only,
+// so (ambient + diffuse) and the specular term are per-face constants of the current camera.  w0..w2 = the
+// ORIGINAL face's world-space corners (also for z-clipped pieces), cpos = camera centre.  Computed once per
+// visible face by the setup kernel; the combine kernel then shades a pixel with one gather.
+struct Shade {
+    float amb_diff, spec;
+};
+__device__ __forceinline__ Shade flat_shade(const float* w0, const float* w1, const float* w2, float cx, float cy, float cz) {
+    const float ax = w1[0] - w0[0], ay = w1[1] - w0[1], az = w1[2] - w0[2];
+    const float bx = w2[0] - w0[0], by = w2[1] - w0[1], bz = w2[2] - w0[2];
+    float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+    float nn = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), kShadeEps);
+    nx /= nn; ny /= nn; nz /= nn;
+    nn = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), kShadeEps);  // F.normalize again in diffuse()/specular()
+    nx /= nn; ny /= nn; nz /= nn;
+    const float ccx = (w0[0] + w1[0] + w2[0]) / 3.0f, ccy = (w0[1] + w1[1] + w2[1]) / 3.0f,
+                ccz = (w0[2] + w1[2] + w2[2]) / 3.0f;
+    float lx = kLightX - ccx, ly = kLightY - ccy, lz = kLightZ - ccz;
+    const float ln = fmaxf(sqrtf(lx * lx + ly * ly + lz * lz), kShadeEps);
+    lx /= ln; ly /= ln; lz /= ln;
+    const float cosang = nx * lx + ny * ly + nz * lz;
+    const float diffuse = kDiffuse * fmaxf(cosang, 0.f);
+    float vx = cx - ccx, vy = cy - ccy, vz = cz - ccz;
+    const float vn = fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), kShadeEps);
+    vx /= vn; vy /= vn; vz /= vn;
+    const float rx = -lx + 2.f * (cosang * nx), ry = -ly + 2.f * (cosang * ny), rz = -lz + 2.f * (cosang * nz);
+    float sa = fmaxf(vx * rx + vy * ry + vz * rz, 0.f) * (cosang > 0.f ? 1.f : 0.f);
+    sa *= sa; sa *= sa; sa *= sa; sa *= sa; sa *= sa; sa *= sa;  // ^64
+    Shade sh;
+    sh.amb_diff = kAmbient + diffuse;
+    sh.spec = kSpecular * sa;
+    return sh;
+}
+
 template <bool GRAD>
 __device__ __forceinline__ void write_record(float* __restrict__ r, uint4* __restrict__ bb, uint4* __restrict__ scan_row,
-                                             int pos, const Tri& t, int face_id, int flags) {
+                                             int pos, const Tri& t, int face_id, int flags, Shade sh) {
     const float x0 = t.v[0].x, y0 = t.v[0].y, x1 = t.v[1].x, y1 = t.v[1].y, x2 = t.v[2].x, y2 = t.v[2].y;
     // [P3D] BarycentricCoordsForward: area = EdgeFunction(v2; v0, v1) + kEpsilon
     const float area = (x2 - x0) * (y1 - y0) - (y2 - y0) * (x1 - x0) + kEpsilon;
@@ -314,13 +348,13 @@ __device__ __forceinline__ void write_record(float* __restrict__ r, uint4* __res
     r4[3] = make_float4(fmin3(x0, x1, x2) - kSqrtBlur, fmax3(x0, x1, x2) + kSqrtBlur, fmin3(y0, y1, y2) - kSqrtBlur,
                         fmax3(y0, y1, y2) + kSqrtBlur);
     r4[4] = make_float4(l01 <= kEpsilon ? -1.0f : 1.0f / l01, l02 <= kEpsilon ? -1.0f : 1.0f / l02,
-                        l12 <= kEpsilon ? -1.0f : 1.0f / l12, 0.f);
+                        l12 <= kEpsilon ? -1.0f : 1.0f / l12, sh.spec);
     if (GRAD) {
         r4[5] = make_float4(t.v[0].t[0], t.v[0].t[1], t.v[0].t[2], t.v[0].t[3]);
         r4[6] = make_float4(t.v[1].t[0], t.v[1].t[1], t.v[1].t[2], t.v[1].t[3]);
         r4[7] = make_float4(t.v[2].t[0], t.v[2].t[1], t.v[2].t[2], t.v[2].t[3]);
     }
-    *bb = t.bbox;
+    *bb = make_uint4(t.bbox.x, t.bbox.y, t.bbox.z, __float_as_uint(sh.amb_diff));  // .w: ambient + diffuse of the face
     // scan row in face order (occ_sort_kernel re-orders dense objects): (pixel bbox, nearest depth key, record index)
     *scan_row = make_uint4(t.bbox.x, t.bbox.y, t.bbox.z, (uint32_t)pos);
 }
@@ -489,7 +523,8 @@ template <bool GRAD>
 __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const float* __restrict__ cam, OccWorkspace ws) {
     __shared__ int s_wcnt[2][4];  // double-buffered: one barrier per 256-face round
     __shared__ int s_rect[4];
-    __shared__ float4 s_rec[4 * 64 * kRecParts];  // per wave: the records of one round, staged for coalesced stores
+    __shared__ float4 s_rec[4 * 64 * kRecPad];  // per wave: the records of one round, staged for coalesced stores
+    // (LDS stride 9 parts = 36 dwords: a 32-dword stride would put every lane's write on the same banks)
     const int eo = blockIdx.x;  // env*3 + object
     const int env = eo / 3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -570,6 +605,7 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
         if (cnt >= 1) {
             if (pos + cnt <= rec_cap) {
                 int x0, y0, x1, y1;
+                const Shade sh = flat_shade(w0, w1, w2, c[C_C], c[C_C + 1], c[C_C + 2]);
                 if (!slow) {
                     Tri tri;
                     {
@@ -583,7 +619,7 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
                         finish_tri(tri, S);
                     }
                     auto emit = [&](float* __restrict__ r) {
-                        write_record<false>(r, bbs + pos, scan + pos, pos, tri, f, 0);
+                        write_record<false>(r, bbs + pos, scan + pos, pos, tri, f, 0, sh);
                         if (GRAD) {
                             // tangents only for the faces that survived culling, stored vertex by vertex
                             VVert q;
@@ -600,7 +636,7 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
                         }
                     };
                     if (staged) {
-                        emit(reinterpret_cast<float*>(&s_rec[(wave * 64 + pre) * kRecParts]));
+                        emit(reinterpret_cast<float*>(&s_rec[(wave * 64 + pre) * kRecPad]));
                     } else {
                         emit(rec + (size_t)pos * OCC_REC_STRIDE);
                     }
@@ -609,11 +645,11 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
                     Tri tmp[2];
                     int fl[2];
                     clip_face_slow<GRAD>(pool_faces, pool_verts, c, S, vo, fo, f, ox, oy, oz, tmp, fl);
-                    write_record<GRAD>(rec + (size_t)pos * OCC_REC_STRIDE, bbs + pos, scan + pos, pos, tmp[0], f, fl[0]);
+                    write_record<GRAD>(rec + (size_t)pos * OCC_REC_STRIDE, bbs + pos, scan + pos, pos, tmp[0], f, fl[0], sh);
                     x0 = tmp[0].tx0; y0 = tmp[0].ty0; x1 = tmp[0].tx1; y1 = tmp[0].ty1;
                     if (cnt == 2) {
                         write_record<GRAD>(rec + (size_t)(pos + 1) * OCC_REC_STRIDE, bbs + pos + 1, scan + pos + 1, pos + 1,
-                                           tmp[1], f, fl[1]);
+                                           tmp[1], f, fl[1], sh);
                         x0 = min(x0, tmp[1].tx0); y0 = min(y0, tmp[1].ty0);
                         x1 = max(x1, tmp[1].tx1); y1 = max(y1, tmp[1].ty1);
                     }
@@ -629,10 +665,10 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
             __builtin_amdgcn_wave_barrier();
             constexpr int kP = GRAD ? kRecParts : 5;  // parts this variant writes
             float4* __restrict__ dst = reinterpret_cast<float4*>(rec + (size_t)wstart * OCC_REC_STRIDE);
-            const float4* src = &s_rec[wave * 64 * kRecParts];
+            const float4* src = &s_rec[wave * 64 * kRecPad];
             for (int i = lane; i < nw * kP; i += 64) {
                 const int rj = i / kP, part = i - rj * kP;
-                dst[rj * kRecParts + part] = src[rj * kRecParts + part];
+                dst[rj * kRecParts + part] = src[rj * kRecPad + part];
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1482,37 +1518,10 @@ __global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bp
             const int mesh = P.sc.scene_mesh[eo];
             const int vo = P.sc.mesh_vert_off[mesh], fo = P.sc.mesh_face_off[mesh];
             const float ox = P.sc.scene_offset[eo * 3], oy = P.sc.scene_offset[eo * 3 + 1], oz = P.sc.scene_offset[eo * 3 + 2];
-            float w[3][3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int vi = P.sc.pool_faces[(size_t)(fo + fid) * 3 + k];
-                const float* pv = P.sc.pool_verts + (size_t)(vo + vi) * 3;
-                w[k][0] = pv[0] + ox;
-                w[k][1] = pv[1] + oy;
-                w[k][2] = pv[2] + oz;
-            }
-            const float ax = w[1][0] - w[0][0], ay = w[1][1] - w[0][1], az = w[1][2] - w[0][2];
-            const float bx = w[2][0] - w[0][0], by = w[2][1] - w[0][1], bz = w[2][2] - w[0][2];
-            float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
-            float nn = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), kShadeEps);
-            nx /= nn; ny /= nn; nz /= nn;
-            nn = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), kShadeEps);  // F.normalize again in diffuse()/specular()
-            nx /= nn; ny /= nn; nz /= nn;
-            const float ccx = (w[0][0] + w[1][0] + w[2][0]) / 3.0f, ccy = (w[0][1] + w[1][1] + w[2][1]) / 3.0f,
-                        ccz = (w[0][2] + w[1][2] + w[2][2]) / 3.0f;
-            float lx = kLightX - ccx, ly = kLightY - ccy, lz = kLightZ - ccz;
-            const float ln = fmaxf(sqrtf(lx * lx + ly * ly + lz * lz), kShadeEps);
-            lx /= ln; ly /= ln; lz /= ln;
-            const float cosang = nx * lx + ny * ly + nz * lz;
-            const float diffuse = kDiffuse * fmaxf(cosang, 0.f);
+            // per-face shading terms from the setup kernel (flat_shade): one gather instead of face -> 3 vertices
+            const float amb_diff = __uint_as_float(reinterpret_cast<const uint4*>(P.ws.rec_bbox)[(size_t)eo * cap + hrec].w);
+            const float spec = r[R_SPEC];
             const float* __restrict__ cm = P.cam + (size_t)env * OCC_CAM_STRIDE;
-            float vx = cm[C_C] - ccx, vy = cm[C_C + 1] - ccy, vz = cm[C_C + 2] - ccz;
-            const float vn = fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), kShadeEps);
-            vx /= vn; vy /= vn; vz /= vn;
-            const float rx = -lx + 2.f * (cosang * nx), ry = -ly + 2.f * (cosang * ny), rz = -lz + 2.f * (cosang * nz);
-            float sa = fmaxf(vx * rx + vy * ry + vz * rz, 0.f) * (cosang > 0.f ? 1.f : 0.f);
-            sa *= sa; sa *= sa; sa *= sa; sa *= sa; sa *= sa; sa *= sa;  // ^64
-            const float spec = kSpecular * sa;
             // texel: white TexturesVertex interpolated with the (unclipped) barycentrics, or the face's atlas
             const float fS = (float)S;
             const float xf = -1.0f + (2.0f * (float)(S - 1 - xi) + 1.0f) / fS;
@@ -1535,10 +1544,14 @@ __global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bp
                     // and V the face's view-space vertices (valid for vertices behind the clip plane too).
                     float V[3][3];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k)
+                    for (int k = 0; k < 3; ++k) {
+                        const int vi = P.sc.pool_faces[(size_t)(fo + fid) * 3 + k];
+                        const float* pv = P.sc.pool_verts + (size_t)(vo + vi) * 3;
+                        const float wx_ = pv[0] + ox, wy_ = pv[1] + oy, wz_ = pv[2] + oz;
 #pragma unroll
                         for (int j = 0; j < 3; ++j)
-                            V[k][j] = w[k][0] * cm[C_R + j] + w[k][1] * cm[C_R + 3 + j] + w[k][2] * cm[C_R + 6 + j] + cm[C_T + j];
+                            V[k][j] = wx_ * cm[C_R + j] + wy_ * cm[C_R + 3 + j] + wz_ * cm[C_R + 6 + j] + cm[C_T + j];
+                    }
                     const float dx = xf / kProjScale, dy = yf / kProjScale, dz = 1.0f;
                     auto tri = [&](const float* a, const float* b) {
                         return dx * (a[1] * b[2] - a[2] * b[1]) + dy * (a[2] * b[0] - a[0] * b[2]) + dz * (a[0] * b[1] - a[1] * b[0]);
@@ -1555,9 +1568,9 @@ __global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bp
                 const float* tx = P.sc.pool_atlas + aoff + (((size_t)fid * Rr + wy) * Rr + wx) * 3;
                 tr = tx[0]; tg = tx[1]; tb = tx[2];
             }
-            cr = (kAmbient + diffuse) * tr + spec;
-            cg = (kAmbient + diffuse) * tg + spec;
-            cb = (kAmbient + diffuse) * tb + spec;
+            cr = amb_diff * tr + spec;
+            cg = amb_diff * tg + spec;
+            cb = amb_diff * tb + spec;
             depth = hz;
         }
         float* __restrict__ ob = P.out.obs + (size_t)env * 4 * S * S + gp;
