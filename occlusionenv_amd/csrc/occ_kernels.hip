@@ -305,23 +305,26 @@ struct Shade {
     float amb_diff, spec;
 };
 __device__ __forceinline__ Shade flat_shade(const float* w0, const float* w1, const float* w2, float cx, float cy, float cz) {
+    // hardware sqrt / rcp (1 ulp) instead of the IEEE sequences: ~1e-7 relative on a colour in [0.5, 1]
+    auto inv_len = [](float x, float y, float z) { return frcp(fmaxf(__builtin_amdgcn_sqrtf(x * x + y * y + z * z), kShadeEps)); };
     const float ax = w1[0] - w0[0], ay = w1[1] - w0[1], az = w1[2] - w0[2];
     const float bx = w2[0] - w0[0], by = w2[1] - w0[1], bz = w2[2] - w0[2];
     float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
-    float nn = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), kShadeEps);
-    nx /= nn; ny /= nn; nz /= nn;
-    nn = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), kShadeEps);  // F.normalize again in diffuse()/specular()
-    nx /= nn; ny /= nn; nz /= nn;
-    const float ccx = (w0[0] + w1[0] + w2[0]) / 3.0f, ccy = (w0[1] + w1[1] + w2[1]) / 3.0f,
-                ccz = (w0[2] + w1[2] + w2[2]) / 3.0f;
+    float in_ = inv_len(nx, ny, nz);
+    nx *= in_; ny *= in_; nz *= in_;
+    in_ = inv_len(nx, ny, nz);  // F.normalize again in diffuse()/specular()
+    nx *= in_; ny *= in_; nz *= in_;
+    const float third = 1.0f / 3.0f;
+    const float ccx = (w0[0] + w1[0] + w2[0]) * third, ccy = (w0[1] + w1[1] + w2[1]) * third,
+                ccz = (w0[2] + w1[2] + w2[2]) * third;
     float lx = kLightX - ccx, ly = kLightY - ccy, lz = kLightZ - ccz;
-    const float ln = fmaxf(sqrtf(lx * lx + ly * ly + lz * lz), kShadeEps);
-    lx /= ln; ly /= ln; lz /= ln;
+    const float il = inv_len(lx, ly, lz);
+    lx *= il; ly *= il; lz *= il;
     const float cosang = nx * lx + ny * ly + nz * lz;
     const float diffuse = kDiffuse * fmaxf(cosang, 0.f);
     float vx = cx - ccx, vy = cy - ccy, vz = cz - ccz;
-    const float vn = fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), kShadeEps);
-    vx /= vn; vy /= vn; vz /= vn;
+    const float iv = inv_len(vx, vy, vz);
+    vx *= iv; vy *= iv; vz *= iv;
     const float rx = -lx + 2.f * (cosang * nx), ry = -ly + 2.f * (cosang * ny), rz = -lz + 2.f * (cosang * nz);
     float sa = fmaxf(vx * rx + vy * ry + vz * rz, 0.f) * (cosang > 0.f ? 1.f : 0.f);
     sa *= sa; sa *= sa; sa *= sa; sa *= sa; sa *= sa; sa *= sa;  // ^64
