@@ -1160,9 +1160,11 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
         int count = 0;          // candidates in THIS lane's list
         float prod = 1.0f, sge = 0.f, sga = 0.f;
         bool thr_on = false;    // set once the pixel's lists have been compacted to its K nearest
-        uint32_t thrT = 0;      // key of the K-th nearest so far: later candidates need key < thrT
-        bool lim_on = false;    // pixel already holds >= K candidates: limT = their largest key bounds the K-th
-        uint32_t limT = 0;      //   nearest from above, so a later candidate needs key < limT to matter
+        bool lim_on = false;    // pixel already holds >= K candidates
+        // key bound of the pixel (equal in its four lanes): a later candidate needs key < bnd to matter.  Lowered to
+        // the largest stored key once the pixel holds >= K candidates (that key bounds the K-th nearest from
+        // above), and to the K-th nearest key itself whenever the lists are compacted
+        uint32_t bnd = 0xFFFFFFFFu;
         uint32_t thrB = 0xFFFFFFFFu;  // block-wide skip key (wave-uniform): faces whose nearest vertex is not
                                       // nearer than this can change neither a pixel's K nearest nor its hard face
         uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;  // key range of this lane's stored candidates
@@ -1174,7 +1176,7 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
 
         auto commit = [&](bool cnd, float z, float qv, float ge, float ga) {
             const uint32_t key = zkey(z);
-            bool acc = cnd && (!thr_on || key < thrT) && (!lim_on || key < limT);
+            bool acc = cnd && key < bnd;
             if (__ballot(acc && count >= OCC_LIST_CAP)) {
                 // rare: a lane's list is full -> keep the pixel's K nearest (over its four lists), go on
                 const bool full = px_any(count >= OCC_LIST_CAP);
@@ -1185,9 +1187,9 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
                 if (full) {
                     count = kept;
                     thr_on = true;
-                    thrT = T;
+                    bnd = min(bnd, T);
                     kmax = T;
-                    acc = cnd && (key < thrT);
+                    acc = cnd && (key < bnd);
                 }
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): leave no load pending across the hot loop
             }
@@ -1292,11 +1294,11 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
                 const int ctot = px_sum_i(count);
                 if (!lim_on && ctot >= K) {
                     lim_on = true;
-                    limT = px_max_u(kmax);
+                    bnd = min(bnd, px_max_u(kmax));
                 }
             }
             uint32_t bound = 0xFFFFFFFFu;
-            if (SOFT) bound = lim_on ? (thr_on ? min(limT, thrT) : limT) : 0xFFFFFFFFu;
+            if (SOFT) bound = bnd;  // 0xFFFFFFFF until the pixel holds >= K candidates
             if (HARD) {
                 const uint32_t hk = hz < 3.0e38f ? zkey(hz) : 0xFFFFFFFFu;  // every lane keeps its own nearest so far
                 bound = SOFT ? max(bound, px_min_u(hk)) : px_min_u(hk);
