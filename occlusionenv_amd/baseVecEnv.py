@@ -90,29 +90,27 @@ class VecEnv(ABC):
 
     def render(self, mode: str, *args, **kwargs):
         try:
-            imgs = self.get_images(*args, **kwargs)
+            frames = self.get_images(*args, **kwargs)
         except NotImplementedError:
             print("Render not defined for {}".format(self))
             return None
-        big = tile_images(imgs)
-        if mode == "human":
-            import cv2  # noqa: WPS433 - optional dependency, as in the reference
-
-            cv2.imshow("vecenv", big[:, :, ::-1])
-            cv2.waitKey(1)
-            return None
+        mosaic = tile_images(frames)
         if mode == "rgb_array":
-            return big
-        raise NotImplementedError
+            return mosaic
+        if mode != "human":
+            raise NotImplementedError
+        import cv2  # optional dependency, as in the reference
+
+        cv2.imshow("vecenv", mosaic[:, :, ::-1])  # RGB -> BGR
+        cv2.waitKey(1)
+        return None
 
     @property
     def unwrapped(self):
         return self.venv.unwrapped if isinstance(self, VecEnvWrapper) else self
 
     def getattr_depth_check(self, name, already_found):
-        if hasattr(self, name) and already_found:
-            return "{0}.{1}".format(type(self).__module__, type(self).__name__)
-        return None
+        return _qualified(self) if (already_found and hasattr(self, name)) else None
 
     def _get_indices(self, indices):
         if indices is None:
@@ -122,85 +120,86 @@ class VecEnv(ABC):
         return indices
 
 
+def _qualified(obj) -> str:
+    cls = type(obj)
+    return "%s.%s" % (cls.__module__, cls.__name__)
+
+
 class VecEnvWrapper(VecEnv):
-    """Wrapper base class delegating to ``self.venv`` (baseVecEnv.py:226-340)."""
+    """Base class of wrappers around another VecEnv held in ``self.venv`` (baseVecEnv.py:226-340): everything
+    that is not overridden is forwarded; attribute lookups fall through the wrapper chain, and a name that two
+    levels of the chain both define is reported as ambiguous instead of silently shadowed."""
+
+    #: methods forwarded verbatim to the wrapped env (generated below)
+    _FORWARDED = ("step_async", "seed", "close", "render", "get_images", "get_attr", "set_attr", "env_method")
 
     def __init__(self, venv, observation_space=None, action_space=None):
         self.venv = venv
-        VecEnv.__init__(self, num_envs=venv.num_envs,
-                        observation_space=observation_space or venv.observation_space,
-                        action_space=action_space or venv.action_space)
-        self.class_attributes = dict(inspect.getmembers(self.__class__))
-
-    def step_async(self, actions):
-        self.venv.step_async(actions)
+        super().__init__(venv.num_envs,
+                         venv.observation_space if observation_space is None else observation_space,
+                         venv.action_space if action_space is None else action_space)
+        self.class_attributes = dict(inspect.getmembers(type(self)))
 
     @abstractmethod
     def reset(self):
-        pass
+        """Wrappers define what a reset returns."""
 
     @abstractmethod
     def step_wait(self):
-        pass
+        """Wrappers define what a finished step returns."""
 
-    def seed(self, seed=None):
-        return self.venv.seed(seed)
-
-    def close(self):
-        return self.venv.close()
-
-    def render(self, *args, **kwargs):
-        return self.venv.render(*args, **kwargs)
-
-    def get_images(self):
-        return self.venv.get_images()
-
-    def get_attr(self, attr_name, indices=None):
-        return self.venv.get_attr(attr_name, indices)
-
-    def set_attr(self, attr_name, value, indices=None):
-        return self.venv.set_attr(attr_name, value, indices)
-
-    def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
-        return self.venv.env_method(method_name, *method_args, indices=indices, **method_kwargs)
+    # ---- attribute resolution through the chain ------------------------------------------------
+    def _get_all_attributes(self):
+        merged = dict(self.__dict__)
+        merged.update(self.class_attributes)
+        return merged
 
     def __getattr__(self, name):
-        blocked = self.getattr_depth_check(name, already_found=False)
-        if blocked is not None:
-            own = "{0}.{1}".format(type(self).__module__, type(self).__name__)
+        # only reached when normal lookup failed on this wrapper
+        owner = self.getattr_depth_check(name, already_found=False)
+        if owner is not None:
             raise AttributeError("Error: Recursive attribute lookup for {0} from {1} is ambiguous and hides "
-                                 "attribute from {2}".format(name, own, blocked))
+                                 "attribute from {2}".format(name, _qualified(self), owner))
         return self.getattr_recursive(name)
-
-    def _get_all_attributes(self):
-        attrs = self.__dict__.copy()
-        attrs.update(self.class_attributes)
-        return attrs
 
     def getattr_recursive(self, name):
         if name in self._get_all_attributes():
             return getattr(self, name)
-        if hasattr(self.venv, "getattr_recursive"):
-            return self.venv.getattr_recursive(name)
-        return getattr(self.venv, name)
+        inner = self.venv
+        return inner.getattr_recursive(name) if hasattr(inner, "getattr_recursive") else getattr(inner, name)
 
     def getattr_depth_check(self, name, already_found):
-        mine = name in self._get_all_attributes()
-        if mine and already_found:
-            return "{0}.{1}".format(type(self).__module__, type(self).__name__)
-        return self.venv.getattr_depth_check(name, True if mine else already_found)
+        here = name in self._get_all_attributes()
+        if here and already_found:
+            return _qualified(self)
+        return self.venv.getattr_depth_check(name, already_found or here)
+
+
+def _make_forwarder(method_name):
+    def forward(self, *args, **kwargs):
+        return getattr(self.venv, method_name)(*args, **kwargs)
+
+    forward.__name__ = method_name
+    forward.__doc__ = "Forwarded to ``self.venv.%s``." % method_name
+    return forward
+
+
+for _name in VecEnvWrapper._FORWARDED:
+    setattr(VecEnvWrapper, _name, _make_forwarder(_name))
+VecEnvWrapper.__abstractmethods__ = frozenset({"reset", "step_wait"})
+del _name
 
 
 class CloudpickleWrapper(object):
-    """Serialise ``var`` with cloudpickle when pickled (baseVecEnv.py:343-356)."""
+    """Carries ``var`` across process boundaries with cloudpickle (closures pickle; baseVecEnv.py:343-356)."""
 
     def __init__(self, var):
         self.var = var
 
     def __getstate__(self):
-        import cloudpickle
+        from cloudpickle import dumps
 
-        return cloudpickle.dumps(self.var)
+        return dumps(self.var)
 
-    def __setstate__(self, obs):
-        self.var = pickle.loads(obs)
+    def __setstate__(self, blob):
+        self.var = pickle.loads(blob)
