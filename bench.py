@@ -127,14 +127,26 @@ def main():
     dev = eng.device
     gen = torch.Generator(device=dev).manual_seed(7 + rank)
     gathered = torch.empty(world * args.envs, rollout.RECORD_FLOATS, device=dev) if world > 1 else None
+    # The per-step record exchange (pack 261 floats/env + one all-gather over RCCL) runs on its own HIP stream,
+    # behind an event recorded after the step's launches: it overlaps the NEXT step's render (bandwidth-bound
+    # pooling + a latency-bound collective next to a VALU-bound raster kernel).
+    side = torch.cuda.Stream(device=dev) if world > 1 else None
+    zeros_lp = torch.zeros(args.envs, device=dev)
 
     def one_step():
         actions = torch.randn(args.envs, 2, device=dev, generator=gen, requires_grad=True)
         obs, rewards, dones, infos = venv.step(actions)
         rewards.sum().backward()
         if world > 1:
-            rec = rollout.pack_records(obs, actions, torch.zeros(args.envs, device=dev), rewards, dones)
-            rollout.all_gather_records(rec, gathered)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(dev))
+            rew, act = rewards.detach(), actions.detach()
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                rec = rollout.pack_records(obs, act, zeros_lp, rew, dones)
+                rollout.all_gather_records(rec, gathered)
+            for t in (obs, act, rew, dones):  # consumed on the side stream: keep their memory until it is done
+                t.record_stream(side)
         return actions.grad
 
     def barrier():
