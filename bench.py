@@ -158,11 +158,19 @@ def main():
         one_step()
     nat.check(lib.occ_profile_enable(1), "occ_profile_enable")
     barrier()
+    trace = os.environ.get("OCC_BENCH_TRACE")
+    stamps = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         g = one_step()
+        if trace:
+            stamps.append(time.perf_counter())
     barrier()
     dt = time.perf_counter() - t0
+    if trace and rank == 0:  # host-side issue time of every step (diagnostics)
+        prev = t0
+        print("[trace] per-step host ms:", " ".join("%.2f" % ((t - p) * 1e3) for p, t in zip([t0] + stamps[:-1], stamps)),
+              file=sys.stderr)
     import ctypes as C
 
     ms_sum, launches = C.c_double(0.0), C.c_int(0)

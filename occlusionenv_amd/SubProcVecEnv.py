@@ -129,6 +129,7 @@ class SimpleVecEnv(VecEnv):
         self._rs_state = np.zeros(reserve, dtype=np.int32)
         self._pending = None                # (report handle, obs, out, infos) of the last step, not yet read
         self._late = []                     # slots refilled AFTER the pairing of the step whose report is pending
+        self._fin_recent = 0.0              # decaying maximum of the number of envs that finished in one step
         self._warm = False
 
     def step_async(self, actions):
@@ -196,6 +197,7 @@ class SimpleVecEnv(VecEnv):
             eng.check_status()
         state = rep[N:N + R].copy()
         assign = rep[N + R:N + 2 * R]
+        self._fin_recent = max(0.9 * self._fin_recent, float(np.count_nonzero(rep[:N])))
         taken = np.nonzero(assign >= 0)[0]
         for r in taken.tolist():
             i = int(assign[r])
@@ -245,8 +247,9 @@ class SimpleVecEnv(VecEnv):
             # with this step); they are rendered from the next step on
             self._refill_reserve(empty)
             self._late = empty
-            # few accepted scenes left (as far as the host knows): do not run ahead, the fallback must come first
-            if int((self._rs_state == nat.RS_READY).sum()) < max(2, R // 2):
+            # few accepted scenes left (as far as the host knows, one step old) compared with how many envs have
+            # been finishing per step lately: do not run ahead, a synchronous fallback would have to come first
+            if int((self._rs_state == nat.RS_READY).sum()) < max(2, int(3 * self._fin_recent) + 2):
                 self._drain()
             return obs, rewards, dones, infos
         obs, rewards, dones, full_state, loss = eng.step(actions)

@@ -874,8 +874,8 @@ __device__ int g_dbg_fault[8];
 // rows into a private u16 histogram in LDS (lane stride kHistStride dwords = conflict-free when lanes agree); the
 // four histograms of a pixel are summed with two cross-lane adds while they are scanned, so the four lanes
 // take identical decisions.  The window [L, L + (1 << kHistBits) << sh) starts at the pixel's own [kmin, kmax] key
-// range, so a few levels resolve the bits below the first differing one.  Key sweeps are pipelined 8 rows
-// deep.  The last sweep reads the payload rows once and takes every key below the boundary bucket plus this
+// range, so a few levels resolve the bits below the first differing one.  Key sweeps are pipelined 16 rows
+// deep (every level is one latency-bound pass over the lists).  The last sweep reads the payload rows once and takes every key below the boundary bucket plus this
 // lane's share of the keys inside it.  Pixels with active == false idle.
 // COMPACT: also moves the kept entries to the front of each list (stable) and returns the new own count.
 // radix-select digit: 4 bits -> 16 u16 buckets = 8 dwords per lane (+1 pad: conflict-free when lanes agree)
@@ -907,15 +907,15 @@ __device__ __forceinline__ void topk_select4(float4* __restrict__ list, uint32_t
     while (__ballot(!done)) {
 #pragma unroll
         for (int i = 0; i < kHistDwords; ++i) h[i] = 0u;
-        for (int e0 = 0; e0 < maxc; e0 += 8) {
-            uint32_t kk[8];
+        for (int e0 = 0; e0 < maxc; e0 += 16) {
+            uint32_t kk[16];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 16; ++i) {
                 const int e = e0 + i;
                 kk[i] = (!done && e < cnt && OCC_BOUND(e < OCC_LIST_CAP, 21, e, cnt)) ? keyp[(size_t)e * 256] : 0u;
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 16; ++i) {
                 const int e = e0 + i;
                 if (!done && e < cnt) {
                     const uint32_t k = kk[i];
