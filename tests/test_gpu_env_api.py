@@ -286,6 +286,28 @@ def test_ppo_rollout_and_update_end_to_end(ds):
     assert all(np.isfinite(st["loss_first"]) and np.isfinite(st["loss_last"]) and np.isfinite(st["mean_reward"]) for st in stats)
 
 
+def test_dataset_generator_and_no_grad_steps(ds, tmp_path):
+    """datasetGenerator.py:76-124 batched (4 runs x 3 frames) + the reader; steps without autograd use the
+    gradient-free kernel variants."""
+    from occlusionenv_amd import dataset_io
+    from environment import OcclusionEnv
+    from SubProcVecEnv import SimpleVecEnv
+
+    N = 16
+    venv = SimpleVecEnv([lambda: OcclusionEnv(ds, img_size=64) for _ in range(N)])
+    n = dataset_io.generate(venv, str(tmp_path), num_frames=3)
+    assert n == N
+    data = dataset_io.OcclusionDataset(str(tmp_path), size=(32, 32))
+    assert len(data) == 3 * N
+    img, label, pos, grad = data[5]
+    assert img.shape == (4, 32, 32) and label.shape == (1, 32, 32) and np.isfinite(grad.numpy()).all()
+    with torch.no_grad():
+        for _ in range(3):
+            obs, rewards, dones, infos = venv.step(torch.randn(N, 2, device="cuda"))
+    assert not rewards.requires_grad and torch.isfinite(rewards).all() and obs.shape == (N, 4, 64, 64)
+    assert set(infos[0].keys()) >= {"full_state", "position", "full_reward"}
+
+
 def test_full_size_properties(ds):
     """BASELINE config 3 size (1024 envs, 128x128, ~5k-face meshes): properties that need no oracle."""
     from tests.parity_utils import make_case
