@@ -441,6 +441,14 @@ __device__ __forceinline__ void world_vertex(const int* __restrict__ pool_faces,
     w[2] = pv[2] + oz;
 }
 
+__device__ __forceinline__ void world_corner(const float* __restrict__ pool_verts, int vo, int vi, float ox, float oy,
+                                             float oz, float* w) {
+    const float* pv = pool_verts + (size_t)(vo + vi) * 3;
+    w[0] = pv[0] + ox;
+    w[1] = pv[1] + oy;
+    w[2] = pv[2] + oz;
+}
+
 template <bool GRAD>
 __device__ __forceinline__ void view_from_world(const CamRT& c, const float* w, VVert& q) {
 #pragma unroll
@@ -556,17 +564,29 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
     bool overflow = false;
     int rx0 = 1 << 20, ry0 = 1 << 20, rx1 = -1, ry1 = -1;  // this thread's share of the object's block rect
     int round = 0;
+    // vertex indices of the NEXT round's face are fetched one round ahead: the index -> vertex -> projection chain
+    // of a round then starts at the vertex gather
+    int vi0 = 0, vi1 = 0, vi2 = 0;
+    if (tid < nF) {
+        const int* pf = pool_faces + (size_t)(fo + tid) * 3;
+        vi0 = pf[0]; vi1 = pf[1]; vi2 = pf[2];
+    }
     for (int base = 0; base < nF; base += 256, round ^= 1) {
         const int f = base + tid;
         int cnt = 0;
         bool slow = false;
         float w0[3], w1[3], w2[3];  // world-space corners: all that a surviving face carries across the barrier
+        const int c0 = vi0, c1 = vi1, c2 = vi2;
+        if (f + 256 < nF) {
+            const int* pf = pool_faces + (size_t)(fo + f + 256) * 3;
+            vi0 = pf[0]; vi1 = pf[1]; vi2 = pf[2];
+        }
         if (f < nF) {
             Tri tri;  // fast path: the unclipped face, positions only (recomputed for the survivors below)
             VVert q0, q1, q2;
-            world_vertex(pool_faces, pool_verts, vo, fo, f, 0, ox, oy, oz, w0);
-            world_vertex(pool_faces, pool_verts, vo, fo, f, 1, ox, oy, oz, w1);
-            world_vertex(pool_faces, pool_verts, vo, fo, f, 2, ox, oy, oz, w2);
+            world_corner(pool_verts, vo, c0, ox, oy, oz, w0);
+            world_corner(pool_verts, vo, c1, ox, oy, oz, w1);
+            world_corner(pool_verts, vo, c2, ox, oy, oz, w2);
             view_from_world<false>(C, w0, q0);
             view_from_world<false>(C, w1, q1);
             view_from_world<false>(C, w2, q2);
