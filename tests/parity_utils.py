@@ -67,8 +67,10 @@ def run_engine(case, img, n_env=None, faces_per_pixel=100, radius=4.0):
                 campos=eng.camera_position.cpu())
 
 
-def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_envs=None, radius=4.0):
+def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_envs=None, radius=4.0, mutate=None):
     case = make_case(n_env, seed, mesh, az_range)
+    if mutate is not None:
+        mutate(case)  # e.g. push an object out of view
     got = run_engine(case, img, radius=radius)
     res = dict(obs_texel_mismatch=0.0, obs_maxabs=0.0, alpha_maxabs=0.0, fs_maxabs=0.0, loss_rel=0.0, reward_abs=0.0, grad_rel=0.0,
                obs0_maxabs=0.0, loss0_rel=0.0, depth_mismatch=0.0)

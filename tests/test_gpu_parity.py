@@ -67,6 +67,23 @@ def test_texture_atlas_z_clipped():
     assert res["depth_mismatch"] < 5e-3 and res["obs_texel_mismatch"] < 5e-3 and res["obs_maxabs"] < TOL, res
 
 
+def test_objects_out_of_view_and_on_the_border():
+    """Empty and ragged inputs: an object entirely off screen (no records, invalid rect), one straddling the
+    image border, one hidden behind the camera; odd env count (the XCD queue padding)."""
+
+    def mutate(case):
+        case["offsets"][0, 1, 0] = 40.0            # env 0: object 2 far off to the side -> not a single record
+        case["offsets"][1, 2] = torch.tensor([1.9, 1.3, 2.0])  # env 1: object 3 cut by the image border
+        case["offsets"][2, 1] = torch.tensor([0.0, 0.0, 9.0])  # env 2: object 2 behind the camera (z_view < 0)
+
+    _check(run_parity_case(n_env=3, img=64, seed=12, mesh="teapot", mutate=mutate))
+
+
+def test_img_512_reference_default_size():
+    """img_size = 512 is the reference's default (environment.py:202)."""
+    _check(run_parity_case(n_env=1, img=512, seed=13, mesh="teapot"))
+
+
 def test_img_256():
     _check(run_parity_case(n_env=1, img=256, seed=8, mesh="teapot"))
 
