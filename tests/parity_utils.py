@@ -72,7 +72,7 @@ def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_
     if mutate is not None:
         mutate(case)  # e.g. push an object out of view
     got = run_engine(case, img, radius=radius)
-    res = dict(obs_texel_mismatch=0.0, obs_maxabs=0.0, alpha_maxabs=0.0, fs_maxabs=0.0, loss_rel=0.0, reward_abs=0.0, grad_rel=0.0,
+    res = dict(alpha_flip_frac=0.0, obs_texel_mismatch=0.0, obs_maxabs=0.0, alpha_maxabs=0.0, fs_maxabs=0.0, loss_rel=0.0, reward_abs=0.0, grad_rel=0.0,
                obs0_maxabs=0.0, loss0_rel=0.0, depth_mismatch=0.0)
     for i in (check_envs if check_envs is not None else range(n_env)):
         env = oracle_env(case, i, img)
@@ -94,7 +94,11 @@ def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_
         d0 = (obs0[0] - got["obs0"][i]).abs()
         res["obs0_maxabs"] = max(res["obs0_maxabs"], float((d0 * ((obs0[0, 3] - got["obs0"][i, 3]).abs() <= 1e-3)).max()))
         al = torch.stack([im[0, ..., 3] for im in env.alphas]).detach()
-        res["alpha_maxabs"] = max(res["alpha_maxabs"], float((al - got["alphas"][i]).abs().max()))
+        dal = (al - got["alphas"][i]).abs()
+        res["alpha_maxabs"] = max(res["alpha_maxabs"], float(dal.max()))
+        # pixels beyond the tolerance: a candidate flipped at the blur boundary (|d alpha| <= 1e-4) or the K-th and
+        # (K+1)-th nearest faces swapped on a rounding-level depth near-tie (dense meshes) - counted, like depth flips
+        res["alpha_flip_frac"] = max(res["alpha_flip_frac"], float((dal > 1e-4).float().mean()))
         res["fs_maxabs"] = max(res["fs_maxabs"], float((info["full_state"][0].detach() - got["fs"][i]).abs().max()))
         lo = float(info["full_reward"])
         res["loss_rel"] = max(res["loss_rel"], abs(lo - float(got["loss"][i])) / max(abs(lo), 1.0))
