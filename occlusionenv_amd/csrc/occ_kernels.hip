@@ -899,11 +899,12 @@ __device__ int g_dbg_fault[8];
 // lane's share of the keys inside it.  Pixels with active == false idle.
 // COMPACT: also moves the kept entries to the front of each list (stable) and returns the new own count.
 // radix-select digit: 4 bits -> 16 u16 buckets = 8 dwords per lane (+1 pad: conflict-free when lanes agree)
-constexpr int kHistBits = 4;
+constexpr int kHistBits = 4;       // in-loop compaction (the staging buffer is live): own small LDS area
+constexpr int kHistBitsFinal = 5;  // final selection: histograms in the idle staging buffer
 constexpr int kHistDwords = (1 << kHistBits) / 2;
 constexpr int kHistStride = kHistDwords + 1;
 
-template <bool COMPACT>
+template <bool COMPACT, int kBits>
 __device__ __forceinline__ void topk_select4(float4* __restrict__ list, uint32_t* __restrict__ hist, int lane,
                                              int cnt, int K, bool active,
                                              uint32_t kmin_own, uint32_t kmax_own, float& pr, float& se, float& sa,
@@ -914,19 +915,20 @@ __device__ __forceinline__ void topk_select4(float4* __restrict__ list, uint32_t
 #else
     const int maxc = wave_max_i(active ? cnt : 0);
 #endif
-    uint32_t* __restrict__ h = hist + lane * kHistStride;
+    constexpr int kDwords = (1 << kBits) / 2, kStride = kDwords + 1;  // u16 buckets, one pad dword per lane
+    uint32_t* __restrict__ h = hist + lane * kStride;
     // the key is component x of the 16-byte row entry: row e of this lane sits 256 dwords further on
     const uint32_t* __restrict__ keyp = reinterpret_cast<const uint32_t*>(list) + lane * 4;
     const uint32_t kmin = px_min_u(kmin_own), kmax = px_max_u(kmax_own);
     uint32_t L = kmin;
     const uint32_t range = kmax >= kmin ? kmax - kmin : 0u;
-    int sh = range ? max(0, (32 - __builtin_clz(range)) - kHistBits) : 0;
+    int sh = range ? max(0, (32 - __builtin_clz(range)) - kBits) : 0;
     int need = K;
     int m_own = 0, mstar_px = 0;
     bool done = !active;
     while (__ballot(!done)) {
 #pragma unroll
-        for (int i = 0; i < kHistDwords; ++i) h[i] = 0u;
+        for (int i = 0; i < kDwords; ++i) h[i] = 0u;
         for (int e0 = 0; e0 < maxc; e0 += 16) {
             uint32_t kk[16];
 #pragma unroll
@@ -940,14 +942,14 @@ __device__ __forceinline__ void topk_select4(float4* __restrict__ list, uint32_t
                 if (!done && e < cnt) {
                     const uint32_t k = kk[i];
                     const uint32_t d = (k - L) >> sh;
-                    if (k >= L && d < (1u << kHistBits)) h[d >> 1] += 1u << (16 * (d & 1u));
+                    if (k >= L && d < (1u << kBits)) h[d >> 1] += 1u << (16 * (d & 1u));
                 }
             }
         }
-        int cum = 0, bstar = (1 << kHistBits) - 1, mstar = 0, cumb = 0, mown = 0;
+        int cum = 0, bstar = (1 << kBits) - 1, mstar = 0, cumb = 0, mown = 0;
         bool found = false;
 #pragma unroll
-        for (int i = 0; i < kHistDwords; ++i) {
+        for (int i = 0; i < kDwords; ++i) {
             const uint32_t wo = h[i];
             uint32_t w = wo;  // joint histogram of the pixel: the four private ones added up
             w += (uint32_t)__shfl_xor((int)w, 16, 64);
@@ -966,7 +968,7 @@ __device__ __forceinline__ void topk_select4(float4* __restrict__ list, uint32_t
             if (mstar == need || sh == 0 || !found) {
                 done = true;
             } else {
-                sh = max(0, sh - kHistBits);
+                sh = max(0, sh - kBits);
             }
         }
     }
@@ -1203,7 +1205,7 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
                 float pr, se, sa;
                 uint32_t T;
                 int kept;
-                topk_select4<true>(mylist, s_hist, lane, count, K, full, kmin, kmax, pr, se, sa, T, kept);
+                topk_select4<true, kHistBits>(mylist, s_hist, lane, count, K, full, kmin, kmax, pr, se, sa, T, kept);
                 if (full) {
                     count = kept;
                     thr_on = true;
@@ -1408,7 +1410,13 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
                 float pr, se, sa;
                 uint32_t T;
                 int kept;
-                topk_select4<false>(mylist, s_hist, lane, count, K, ovf, kmin, kmax, pr, se, sa, T, kept);
+                // the staging buffer is idle now: its LDS holds the wider (5-bit digit) histograms of the final
+                // selection - one level less on average, each level being a pass over the lists in memory
+                static_assert(sizeof(float4) * kStage * kRecParts >= 64 * ((1 << kHistBitsFinal) / 2 + 1) * 4, "hist");
+                __syncthreads();
+                topk_select4<false, kHistBitsFinal>(mylist, reinterpret_cast<uint32_t*>(s_stage), lane, count, K, ovf, kmin,
+                                                    kmax, pr, se, sa, T, kept);
+                __syncthreads();
                 if (ovf) {
                     prod = pr;
                     sge = se;
