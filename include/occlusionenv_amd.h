@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define OCC_ABI_VERSION 1
+#define OCC_ABI_VERSION 2
 
 /* return codes */
 #define OCC_OK 0
@@ -86,6 +86,9 @@ typedef struct OccScene {
     const float* pool_atlas;        /* packed (sum over textured meshes of F*R*R*3) */
     const int64_t* mesh_atlas_off;  /* (n_meshes) float offset of each mesh's atlas in pool_atlas, -1 = white vertices */
     int32_t atlas_res;              /* R */
+    /* optional (n_env) int32: nonzero = do not render this scene row in this launch (its outputs are left
+     * untouched); used for reserve slots that are not under test (occ_auto_reset keeps it up to date) */
+    const int32_t* skip;
 } OccScene;
 
 /* Caller-allocated scratch; sizes from occ_workspace_query(). */
@@ -207,9 +210,12 @@ int occ_reset_commit(const int32_t* pairs, int n, float* el, float* az, float* r
  * -- rendered by a step; loss > 0.1 or 10th try --> OCC_RS_READY (else back to EMPTY, try count kept) -- taken by
  * a finished env --> EMPTY (tries = 0).  Only the host leaves EMPTY, only the device leaves PENDING / READY.
  *
- * One call = two launches: (1) a single block ages the PENDING slots, lists finished envs and READY slots in
- * index order and pairs them; (2) every pair copies the slot's state into the env's rows (as occ_reset_commit),
- * saving the env's final observation to term_obs[slot] first (info["terminal_observation"]).
+ * One call = three launches: (0) the rows this step rendered for PENDING slots (observation, full_state, loss) are
+ * copied into the persistent OccReserveStore - READY slots are not rendered again (OccScene.skip), their last render
+ * stays valid; (1) a single block ages the PENDING slots, lists finished envs and READY slots in index order, pairs
+ * them and refreshes the skip mask (rendered next step = PENDING only); (2) every pair copies the slot's stored
+ * state into the env's rows (as occ_reset_commit), saving the env's final observation to term_obs[slot] first
+ * (info["terminal_observation"]).
  * report (n_env + 2*n_reserve + 2 int32): [0,n_env) done | [n_env, +n_reserve) slot state AFTER the call |
  * [.., +n_reserve) env that took the slot this call or -1 | any status bit | finished envs left without a slot.
  * pairs: scratch, 2 + 2*n_reserve int32.  Arrays of OccEnvState hold n_env + n_reserve rows except
@@ -232,16 +238,24 @@ typedef struct OccEnvState {
     float* scene_offset;
 } OccEnvState;
 
+/* Persistent copy of what the last render of every reserve slot produced (a slot is only rendered while PENDING). */
+typedef struct OccReserveStore {
+    float* obs;        /* (n_reserve,4,S,S) */
+    float* full_state; /* (n_reserve,S,S,4) */
+    float* loss;       /* (n_reserve) */
+    int32_t* skip;     /* (n_env + n_reserve) the OccScene.skip mask; rows >= n_env maintained here */
+} OccReserveStore;
+
 int occ_auto_reset(const uint8_t* done, const float* loss_all, const int32_t* status, int n_env, int n_reserve,
-                   int32_t* rs_state, int32_t* rs_tries, const OccEnvState* st, float* obs_all, float* term_obs, int img,
-                   int32_t* pairs, int32_t* report, void* stream);
+                   int32_t* rs_state, int32_t* rs_tries, const OccEnvState* st, float* obs_all, const float* full_state_all,
+                   const OccReserveStore* store, float* term_obs, int img, int32_t* pairs, int32_t* report, void* stream);
 
 /*
  * Host -> reserve: n packed rows of 13 words (slot, mesh id x3, offset x9 as float bits) already in device
  * memory; scatters them into scene_mesh / scene_offset rows n_env + slot and marks the slots OCC_RS_PENDING.
  */
 int occ_reserve_refill(const int32_t* packed, int n, int n_env, int n_reserve, int32_t* scene_mesh, float* scene_offset,
-                       int32_t* rs_state, void* stream);
+                       int32_t* rs_state, int32_t* skip, void* stream);
 
 /*
  * Measurement hooks (bench.py only; not part of the reference surface).  While enabled, occ_render

@@ -168,11 +168,15 @@ class SimpleVecEnv(VecEnv):
             res = eng.evaluate_scenes([self._rs_scene[r][0] for r in pending], [self._rs_scene[r][1] for r in pending],
                                       4.0, 0.0, 0.0)
             ok = (res["loss"] > 0.1).cpu().tolist()
-            redraw = []
+            redraw, acc_slots, acc_cand = [], [], []
             for j, r in enumerate(pending):
                 tries[r] += 1
-                if not (ok[j] or tries[r] >= 10):
+                if ok[j] or tries[r] >= 10:
+                    acc_slots.append(r)
+                    acc_cand.append(j)
+                else:
                     redraw.append(r)
+            eng.install_reserve(acc_slots, res, acc_cand)  # READY slots are never rendered by a step: store this render
             self._refill_reserve(redraw)
             pending = redraw
         self._rs_state[:] = nat.RS_READY
@@ -204,7 +208,7 @@ class SimpleVecEnv(VecEnv):
             # save final observation where user can get it, then reset (SubProcVecEnv.py:211-214)
             infos.set(i, "terminal_observation", pend["term"][r:r + 1])
             self.envs[i]._scene = self._rs_scene[r]
-            self.envs[i].image = out["full_state_all"][N + r:N + r + 1]
+            self.envs[i].image = eng._res_fs[r:r + 1].clone()  # the slot's stored render (it will be overwritten)
         if rep[N + 2 * R + 1]:  # reserve exhausted: synchronous batched reset for the rest
             done_envs = set(np.nonzero(rep[:N])[0].tolist())
             left = sorted(done_envs - set(int(assign[r]) for r in taken.tolist()))

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OCC_HIP_LIB") or os.path.join(_HERE, "libocc_hip.so")
 
 # layout constants (must match include/occlusionenv_amd.h)
-ABI_VERSION = 1
+ABI_VERSION = 2
 CAM_STRIDE = 48
 REC_STRIDE = 32
 TILE = 8
@@ -42,6 +42,7 @@ class OccScene(C.Structure):
         ("pool_atlas", C.c_void_p),
         ("mesh_atlas_off", C.c_void_p),
         ("atlas_res", C.c_int32),
+        ("skip", C.c_void_p),
     ]
 
 
@@ -102,6 +103,10 @@ class OccEnvState(C.Structure):
                                           "scene_mesh", "scene_offset")]
 
 
+class OccReserveStore(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("obs", "full_state", "loss", "skip")]
+
+
 RS_EMPTY, RS_PENDING, RS_READY = 0, 1, 2
 
 #: every symbol include/occlusionenv_amd.h declares: name -> (restype, argtypes)
@@ -121,8 +126,10 @@ SYMBOLS = {
     "occ_step_flags": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "occ_reset_commit": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 13 + [C.c_int, C.c_void_p]),
     "occ_auto_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                 C.POINTER(OccEnvState), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "occ_reserve_refill": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                 C.POINTER(OccEnvState), C.c_void_p, C.c_void_p, C.POINTER(OccReserveStore), C.c_void_p,
+                                 C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "occ_reserve_refill": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
     "occ_profile_enable": (C.c_int, [C.c_int]),
     "occ_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }

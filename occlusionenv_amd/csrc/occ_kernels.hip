@@ -539,6 +539,16 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
     const int eo = blockIdx.x;  // env*3 + object
     const int env = eo / 3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (sc.skip && sc.skip[env]) {  // scene row not rendered in this launch: no records, no work items
+        if (tid == 0) {
+            ws.nrec[eo] = 0;
+            ws.objrect[eo * 4 + 0] = 1 << 20;
+            ws.objrect[eo * 4 + 1] = 1 << 20;
+            ws.objrect[eo * 4 + 2] = -1;
+            ws.objrect[eo * 4 + 3] = -1;
+        }
+        return;
+    }
     const int mesh = sc.scene_mesh[eo];
     const int vo = sc.mesh_vert_off[mesh];
     const int fo = sc.mesh_face_off[mesh];
@@ -1464,6 +1474,7 @@ __global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bp
     __shared__ float s_red[4][3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int env = blockIdx.x / bpe, blk = blockIdx.x - env * bpe;
+    if (P.sc.skip && P.sc.skip[env]) return;  // outputs of a skipped scene row stay untouched
     const int S = P.sc.img;
     const int pix = blk * 256 + tid;
     const bool live = pix < S * S;
@@ -1618,8 +1629,10 @@ __global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bp
 // per-env fixed-order reduction of the tile partials
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void occ_reduce_kernel(const float* __restrict__ partials, int ntiles,
-                                                        float* __restrict__ loss, float* __restrict__ grad_elaz) {
+                                                        float* __restrict__ loss, float* __restrict__ grad_elaz,
+                                                        const int* __restrict__ skip) {
     const int env = blockIdx.x, lane = threadIdx.x;
+    if (skip && skip[env]) return;
     const float4* __restrict__ p = reinterpret_cast<const float4*>(partials) + (size_t)env * ntiles;
     float l = 0.f, ge = 0.f, ga = 0.f;
     for (int t = lane; t < ntiles; t += 64) {
@@ -1733,7 +1746,7 @@ __global__ __launch_bounds__(256) void occ_commit_kernel(CommitArgs a) {
 struct PairArgs {
     const uint8_t* done; const float* loss_all; const int* status;
     int n_env, n_res;
-    int* rs_state; int* rs_tries; int* pairs; int* report;
+    int* rs_state; int* rs_tries; int* pairs; int* report; int* skip;
 };
 
 // ordered compaction helper: exclusive prefix of flag over a 1024-thread block (16 waves)
@@ -1811,6 +1824,7 @@ __global__ __launch_bounds__(1024) void occ_pair_kernel(PairArgs a) {
         }
         a.rs_state[tid] = st;
         a.report[N + tid] = st;
+        a.skip[N + tid] = (st != OCC_RS_PENDING) ? 1 : 0;  // only slots under test are rendered by the next step
     }
     if (tid == 0) {
         a.pairs[0] = npair;
@@ -1819,10 +1833,33 @@ __global__ __launch_bounds__(1024) void occ_pair_kernel(PairArgs a) {
     }
 }
 
+// rows this step rendered for PENDING slots -> persistent store (runs BEFORE the pairing changes any state)
+struct StashArgs {
+    const int* rs_state; const float* obs_all; const float* fs_all; const float* loss_all;
+    OccReserveStore store;
+    int img, n_env;
+};
+constexpr int kStashBlocks = 16;
+__global__ __launch_bounds__(256) void occ_stash_kernel(StashArgs a) {
+    const int r = blockIdx.x;
+    if (a.rs_state[r] != OCC_RS_PENDING) return;
+    const int tid = threadIdx.x, y = blockIdx.y;
+    const size_t S2 = (size_t)a.img * a.img, src = (size_t)(a.n_env + r);
+    const float4* o4 = reinterpret_cast<const float4*>(a.obs_all + src * 4 * S2);
+    const float4* f4 = reinterpret_cast<const float4*>(a.fs_all + src * 4 * S2);
+    float4* od = reinterpret_cast<float4*>(a.store.obs + (size_t)r * 4 * S2);
+    float4* fd = reinterpret_cast<float4*>(a.store.full_state + (size_t)r * 4 * S2);
+    for (size_t i = (size_t)y * 256 + tid; i < S2; i += (size_t)kStashBlocks * 256) {
+        od[i] = o4[i];
+        fd[i] = f4[i];
+    }
+    if (y == 0 && tid == 0) a.store.loss[r] = a.loss_all[src];
+}
+
 struct AutoCommitArgs {
     const int* pairs;
     OccEnvState st;
-    float* obs_all; float* term_obs; const float* loss_all;
+    float* obs_all; float* term_obs; const float* res_obs; const float* res_loss;
     int img, n_env;
 };
 constexpr int kCommitObsBlocks = 8, kCommitAlphaBlocks = 6;
@@ -1837,7 +1874,7 @@ __global__ __launch_bounds__(256) void occ_auto_commit_kernel(AutoCommitArgs a) 
             a.st.el[dst] = a.st.el[src];
             a.st.az[dst] = a.st.az[src];
             a.st.radius[dst] = a.st.radius[src];
-            const float l = a.loss_all[src];
+            const float l = a.res_loss[src - a.n_env];
             a.st.full_reward[dst] = l;
             a.st.object_mass[dst] = l + 1.0f;
         }
@@ -1848,8 +1885,8 @@ __global__ __launch_bounds__(256) void occ_auto_commit_kernel(AutoCommitArgs a) 
         if (tid < 9) a.st.scene_offset[dst * 9 + tid] = a.st.scene_offset[src * 9 + tid];
         if (tid < OCC_CAM_STRIDE) a.st.cam[(size_t)dst * OCC_CAM_STRIDE + tid] = a.st.cam[(size_t)src * OCC_CAM_STRIDE + tid];
     } else if (y <= kCommitObsBlocks) {
-        // final observation -> term_obs[slot], reset observation -> obs[env] (same element range, same thread)
-        const float4* s4 = reinterpret_cast<const float4*>(a.obs_all + (size_t)src * 4 * S2);
+        // final observation -> term_obs[slot], stored reset observation -> obs[env] (same element range, same thread)
+        const float4* s4 = reinterpret_cast<const float4*>(a.res_obs + (size_t)(src - a.n_env) * 4 * S2);
         float4* d4 = reinterpret_cast<float4*>(a.obs_all + (size_t)dst * 4 * S2);
         float4* t4 = reinterpret_cast<float4*>(a.term_obs + (size_t)(src - a.n_env) * 4 * S2);
         for (size_t i = (size_t)(y - 1) * 256 + tid; i < S2; i += (size_t)kCommitObsBlocks * 256) {
@@ -1866,7 +1903,7 @@ __global__ __launch_bounds__(256) void occ_auto_commit_kernel(AutoCommitArgs a) 
 
 __global__ __launch_bounds__(64) void occ_refill_kernel(const int* __restrict__ packed, int n, int n_env, int n_res,
                                                         int* __restrict__ scene_mesh, float* __restrict__ scene_offset,
-                                                        int* __restrict__ rs_state) {
+                                                        int* __restrict__ rs_state, int* __restrict__ skip) {
     const int k = blockIdx.x, tid = threadIdx.x;
     if (k >= n) return;
     const int* row = packed + 13 * k;
@@ -1875,7 +1912,10 @@ __global__ __launch_bounds__(64) void occ_refill_kernel(const int* __restrict__ 
     const int e = n_env + slot;
     if (tid < 3) scene_mesh[e * 3 + tid] = row[1 + tid];
     if (tid < 9) scene_offset[e * 9 + tid] = __int_as_float(row[4 + tid]);
-    if (tid == 0) rs_state[slot] = OCC_RS_PENDING;
+    if (tid == 0) {
+        rs_state[slot] = OCC_RS_PENDING;
+        skip[e] = 0;  // rendered from the next launch on
+    }
 }
 
 
@@ -2266,7 +2306,7 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
     if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
     if (soft && (out->loss || out->grad_elaz)) {
         hipLaunchKernelGGL(occ_reduce_kernel, dim3(N), dim3(64), 0, st, ws->partials, bpe, out->loss,
-                           grad ? out->grad_elaz : nullptr);
+                           grad ? out->grad_elaz : nullptr, scene->skip);
         if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
     }
     return OCC_OK;
@@ -2330,28 +2370,31 @@ extern "C" int occ_reset_commit(const int32_t* pairs, int n, float* el, float* a
 }
 
 extern "C" int occ_auto_reset(const uint8_t* done, const float* loss_all, const int32_t* status, int n_env, int n_reserve,
-                              int32_t* rs_state, int32_t* rs_tries, const OccEnvState* st, float* obs_all, float* term_obs,
-                              int img, int32_t* pairs, int32_t* report, void* stream) {
+                              int32_t* rs_state, int32_t* rs_tries, const OccEnvState* st, float* obs_all,
+                              const float* full_state_all, const OccReserveStore* store, float* term_obs, int img,
+                              int32_t* pairs, int32_t* report, void* stream) {
     if (!done || !loss_all || !status || n_env <= 0 || n_reserve <= 0 || n_reserve > 512 || !rs_state || !rs_tries || !st ||
-        !obs_all || !term_obs || img <= 0 || !pairs || !report)
+        !obs_all || !full_state_all || !store || !term_obs || img <= 0 || !pairs || !report)
         return OCC_ERR_ARG;
     if (!st->el || !st->az || !st->radius || !st->campos || !st->cam || !st->alphas || !st->full_reward || !st->object_mass ||
-        !st->scene_mesh || !st->scene_offset)
+        !st->scene_mesh || !st->scene_offset || !store->obs || !store->full_state || !store->loss || !store->skip)
         return OCC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    PairArgs pa{done, loss_all, status, n_env, n_reserve, rs_state, rs_tries, pairs, report};
+    StashArgs sa{rs_state, obs_all, full_state_all, loss_all, *store, img, n_env};
+    hipLaunchKernelGGL(occ_stash_kernel, dim3(n_reserve, kStashBlocks), dim3(256), 0, s, sa);
+    PairArgs pa{done, loss_all, status, n_env, n_reserve, rs_state, rs_tries, pairs, report, store->skip};
     hipLaunchKernelGGL(occ_pair_kernel, dim3(1), dim3(1024), 0, s, pa);
-    AutoCommitArgs ca{pairs, *st, obs_all, term_obs, loss_all, img, n_env};
+    AutoCommitArgs ca{pairs, *st, obs_all, term_obs, store->obs, store->loss, img, n_env};
     hipLaunchKernelGGL(occ_auto_commit_kernel, dim3(n_reserve, 1 + kCommitObsBlocks + kCommitAlphaBlocks), dim3(256), 0, s, ca);
     return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
 }
 
 extern "C" int occ_reserve_refill(const int32_t* packed, int n, int n_env, int n_reserve, int32_t* scene_mesh,
-                                  float* scene_offset, int32_t* rs_state, void* stream) {
+                                  float* scene_offset, int32_t* rs_state, int32_t* skip, void* stream) {
     if (n == 0) return OCC_OK;
-    if (!packed || n < 0 || n_env <= 0 || n_reserve <= 0 || !scene_mesh || !scene_offset || !rs_state) return OCC_ERR_ARG;
+    if (!packed || n < 0 || n_env <= 0 || n_reserve <= 0 || !scene_mesh || !scene_offset || !rs_state || !skip) return OCC_ERR_ARG;
     hipLaunchKernelGGL(occ_refill_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, packed, n, n_env, n_reserve, scene_mesh,
-                       scene_offset, rs_state);
+                       scene_offset, rs_state, skip);
     return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
 }
 

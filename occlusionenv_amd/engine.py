@@ -100,6 +100,14 @@ class OcclusionEngine:
             self._refill_host = [torch.zeros(self.R, 13, dtype=torch.int32).pin_memory() for _ in range(2)]
             self._report_host = [torch.zeros(N + 2 * self.R + 2, dtype=torch.int32).pin_memory() for _ in range(2)]
             self._flip = 0
+            # what the last render of every slot produced: a slot is rendered only while PENDING (skip mask), a
+            # READY slot keeps its stored observation / occlusion image / loss until an env takes it
+            S = self.S
+            self._res_obs = torch.zeros(self.R, 4, S, S, **f32)
+            self._res_fs = torch.zeros(self.R, S, S, 4, **f32)
+            self._res_loss = torch.zeros(self.R, **f32)
+            self._skip = torch.zeros(NT, **i32)
+            self._skip[N:] = 1  # EMPTY slots are not rendered
 
     # ---- scenes ---------------------------------------------------------------------------
     def set_scene(self, env_ids, mesh_ids, offsets) -> None:
@@ -112,7 +120,7 @@ class OcclusionEngine:
         self.scene_offset[idx] = torch.as_tensor(offsets, dtype=torch.float32).reshape(-1, 3, 3).to(self.device)
 
     # ---- workspace ------------------------------------------------------------------------
-    def _scene_struct(self, n, scene_mesh, scene_offset) -> nat.OccScene:
+    def _scene_struct(self, n, scene_mesh, scene_offset, skip=None) -> nat.OccScene:
         pv, pf, vo, fo = self.pool.device_tensors()
         sc = nat.OccScene()
         sc.pool_verts, sc.pool_faces = pv.data_ptr(), pf.data_ptr()
@@ -123,6 +131,8 @@ class OcclusionEngine:
         atlas, aoff = self.pool.atlas_tensors()
         if atlas is not None:
             sc.pool_atlas, sc.mesh_atlas_off, sc.atlas_res = atlas.data_ptr(), aoff.data_ptr(), self.pool.atlas_res
+        if skip is not None:
+            sc.skip = skip.data_ptr()
         return sc
 
     def _rec_cap(self) -> int:
@@ -322,8 +332,23 @@ class OcclusionEngine:
 
     def set_reserve_state(self, state, tries) -> None:
         """Overwrite the device-side slot states (host-driven warm-up only; no step may be in flight)."""
-        self.rs_state.copy_(torch.as_tensor(np.asarray(state), dtype=torch.int32))
+        st = torch.as_tensor(np.asarray(state), dtype=torch.int32)
+        self.rs_state.copy_(st)
         self.rs_tries.copy_(torch.as_tensor(np.asarray(tries), dtype=torch.int32))
+        self._skip[self.N:].copy_((st != nat.RS_PENDING).to(torch.int32))
+
+    def install_reserve(self, slots, res, cand) -> None:
+        """Store candidates ``cand`` of an evaluate_scenes() result as the last render of reserve ``slots`` (the
+        host-driven warm-up accepted them; they will be READY without ever being rendered by a step launch)."""
+        if not len(slots):
+            return
+        sl = torch.as_tensor(slots, dtype=torch.long, device=self.device)
+        c = torch.as_tensor(cand, dtype=torch.long, device=self.device)
+        self._res_obs[sl] = res["obs"][c]
+        self._res_fs[sl] = res["full_state"][c]
+        self._res_loss[sl] = res["loss"][c]
+        self._alphas_all[self.N + sl] = res["alphas"][c]
+        self._cam_all[self.N + sl] = res["cam"][c]
 
     def refill_reserve(self, slots, mesh_ids, offsets) -> None:
         """Hand new candidate scenes to EMPTY reserve slots: one packed H2D copy + occ_reserve_refill (scatter,
@@ -349,7 +374,7 @@ class OcclusionEngine:
         h[:n, 4:13] = off.view(np.int32)
         self._refill_dev[:n].copy_(host[:n], non_blocking=True)
         nat.check(self.lib.occ_reserve_refill(_p(self._refill_dev), n, self.N, self.R, _p(self._mesh_all), _p(self._off_all),
-                                              _p(self.rs_state), self._stream()), "occ_reserve_refill")
+                                              _p(self.rs_state), _p(self._skip), self._stream()), "occ_reserve_refill")
 
     def auto_reset(self, out) -> dict:
         """Device-side auto-reset of the envs that finished in the step which produced ``out`` (pairing with READY
@@ -363,9 +388,13 @@ class OcclusionEngine:
         st.campos, st.cam, st.alphas = self.camera_position.data_ptr(), self._cam_all.data_ptr(), self._alphas_all.data_ptr()
         st.full_reward, st.object_mass = self.full_reward.data_ptr(), self.object_mass.data_ptr()
         st.scene_mesh, st.scene_offset = self._mesh_all.data_ptr(), self._off_all.data_ptr()
+        store = nat.OccReserveStore()
+        store.obs, store.full_state, store.loss = self._res_obs.data_ptr(), self._res_fs.data_ptr(), self._res_loss.data_ptr()
+        store.skip = self._skip.data_ptr()
         nat.check(self.lib.occ_auto_reset(_p(out["done_u8"]), _p(out["loss_all"]), _p(self.status), N, R, _p(self.rs_state),
-                                          _p(self.rs_tries), C.byref(st), _p(out["obs_all"]), _p(term), S, _p(self._pairs),
-                                          _p(report), self._stream()), "occ_auto_reset")
+                                          _p(self.rs_tries), C.byref(st), _p(out["obs_all"]), _p(out["full_state_all"]),
+                                          C.byref(store), _p(term), S, _p(self._pairs), _p(report), self._stream()),
+                  "occ_auto_reset")
         self._rflip = getattr(self, "_rflip", 0) ^ 1
         host = self._report_host[self._rflip]
         host.copy_(report, non_blocking=True)
@@ -446,7 +475,7 @@ class OcclusionEngine:
             g = torch.empty(NT, 2, **f32)
             ro.grad_elaz = g.data_ptr()
             out["grad_elaz"] = g[:N]
-        sc = self._scene_struct(NT, self._mesh_all, self._off_all)
+        sc = self._scene_struct(NT, self._mesh_all, self._off_all, self._skip)
         ver = self.pool.version
         cam_args = (nat.CAM_STEP, _p(actions), _p(self._el_all), _p(self._az_all), _p(self._rad_all), _p(self._cam_all),
                     _p(self.camera_position), N, st)
@@ -454,7 +483,7 @@ class OcclusionEngine:
             pre_launch()
             if self.pool.version != ver:  # a fallback reset inside pre_launch added meshes: the pool was re-packed
                 ws = self._ensure_workspace()
-                sc = self._scene_struct(NT, self._mesh_all, self._off_all)
+                sc = self._scene_struct(NT, self._mesh_all, self._off_all, self._skip)
         nat.check(self.lib.occ_camera(*cam_args), "occ_camera")
         if not self._reserve_cam_done:  # reset() camera of the reserve rows: radius 4, az = el = 0, never changes
             nat.check(self.lib.occ_camera(nat.CAM_LOOKAT, None, _p(self._el_all[N:]), _p(self._az_all[N:]),
