@@ -119,8 +119,9 @@ class SimpleVecEnv(VecEnv):
         dev = torch.device(f"cuda:{torch.cuda.current_device()}") if torch.cuda.is_available() else env.device
         # reserve slots: speculative auto-reset scenes rendered inside every batched step (see engine.py)
         same_data = all(e.shapenet_dataset is env.shapenet_dataset for e in self.envs)
-        # ~0.8 % of the envs finish per step and ~58 % of the candidates pass: N/16 slots keep the reserve from running dry
-        reserve = min(512, max(self.num_envs // 16, 2 if self.num_envs >= 16 else 0)) if same_data else 0
+        # ~0.8 % of the envs finish per step and ~58 % of the candidates pass; only slots under test are rendered, so
+        # a generous N/8 slots cost next to nothing and keep the reserve far from running dry
+        reserve = min(512, max(self.num_envs // 8, 2 if self.num_envs >= 16 else 0)) if same_data else 0
         self.engine = OcclusionEngine(shared_pool(dev), self.num_envs, env.img_size, device=dev, reserve=reserve)
         for i, e in enumerate(self.envs):
             e._attach(self.engine, i)
