@@ -79,6 +79,14 @@ def test_objects_out_of_view_and_on_the_border():
     _check(run_parity_case(n_env=3, img=64, seed=12, mesh="teapot", mutate=mutate))
 
 
+def test_far_camera_thousands_of_candidates_per_pixel():
+    """radius 30: a 20 480-face object covers a handful of pixels, every one of which collects thousands of
+    candidates -> the K-buffer lists fill up (OCC_LIST_CAP = 512 per lane) and are compacted inside the loop of the
+    shipped library, pruning bounds tighten while faces are still arriving."""
+    res = run_parity_case(n_env=2, img=64, seed=14, mesh="mixed", radius=30.0)
+    _check(res, grad_tol=5e-3)
+
+
 def test_img_512_reference_default_size():
     """img_size = 512 is the reference's default (environment.py:202)."""
     _check(run_parity_case(n_env=1, img=512, seed=13, mesh="teapot"))
