@@ -18,6 +18,8 @@
  *   - the operator-level replacement of _C.rasterize_meshes / _C.rasterize_meshes_backward (K-buffer in
  *     PyTorch3D layout, naive path)                                 -> occ_rasterize_meshes_naive,
  *                                                                      occ_rasterize_meshes_backward_dists
+ *   - PyTorch3D sigmoid_alpha_blend on those K-buffers (SoftSilhouetteShader, environment.py:263)
+ *                                                                   -> occ_sigmoid_alpha_blend_fwd / _bwd
  *   - SimpleVecEnv.step_wait's per-step host hand-off and auto-reset (SubProcVecEnv.py:209-218)
  *                                                                   -> occ_step_flags, occ_reset_commit,
  *                                                                      occ_auto_reset, occ_reserve_refill
@@ -180,6 +182,16 @@ int occ_rasterize_meshes_backward_dists(const float* face_verts, const int64_t* 
                                         int64_t n_faces, int n_meshes, int H, int W, int faces_per_pixel,
                                         int perspective_correct, int clip_barycentric_coords, float* grad_face_verts,
                                         void* stream);
+
+/*
+ * [P3D] sigmoid_alpha_blend (SoftSilhouetteShader, environment.py:263) on K-buffers in PyTorch3D layout:
+ *   alpha[p] = 1 - prod_k (1 - sigmoid(-dists[p,k] / sigma) * [pix_to_face[p,k] >= 0]),   images (n_pix,4) RGBA, RGB = 1.
+ * Backward: grad_dists[p,k] from grad_images (only the alpha channel carries gradient).
+ */
+int occ_sigmoid_alpha_blend_fwd(const float* dists, const int64_t* pix_to_face, int64_t n_pix, int faces_per_pixel,
+                                float sigma, float* images, void* stream);
+int occ_sigmoid_alpha_blend_bwd(const float* dists, const int64_t* pix_to_face, const float* grad_images, int64_t n_pix,
+                                int faces_per_pixel, float sigma, float* grad_dists, void* stream);
 
 /*
  * Host hand-off of SimpleVecEnv.step_wait (SubProcVecEnv.py:209-218): one int32 buffer

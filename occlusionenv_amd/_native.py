@@ -123,6 +123,9 @@ SYMBOLS = {
                                              C.c_int, C.c_int] + [C.c_void_p] * 5),
     "occ_rasterize_meshes_backward_dists": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                                       C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "occ_sigmoid_alpha_blend_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "occ_sigmoid_alpha_blend_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p,
+                                              C.c_void_p]),
     "occ_step_flags": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "occ_reset_commit": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 13 + [C.c_int, C.c_void_p]),
     "occ_auto_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

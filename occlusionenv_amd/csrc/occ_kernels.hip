@@ -1740,6 +1740,46 @@ __global__ __launch_bounds__(256) void occ_commit_kernel(CommitArgs a) {
 }
 
 
+// [P3D] sigmoid_alpha_blend on K-buffers (operator level; the fused path never materialises them).  One thread per
+// pixel, plain IEEE arithmetic in PyTorch3D's order: prob = sigmoid(-d / sigma) * mask, alpha = 1 - prod(1 - prob).
+__global__ __launch_bounds__(256) void occ_blend_fwd_kernel(const float* __restrict__ dists, const int64_t* __restrict__ p2f,
+                                                            long n_pix, int K, float sigma, float* __restrict__ images) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pix) return;
+    float prod = 1.0f;
+    for (int k = 0; k < K; ++k) {
+        const float m = p2f[p * K + k] >= 0 ? 1.0f : 0.0f;
+        const float prob = m / (1.0f + expf(dists[p * K + k] / sigma));
+        prod *= 1.0f - prob;
+    }
+    reinterpret_cast<float4*>(images)[p] = make_float4(1.0f, 1.0f, 1.0f, 1.0f - prod);
+}
+
+// d alpha / d d_k = (prod_{j != k} (1 - prob_j)) * prob_k (1 - prob_k) / sigma   (masked entries carry no gradient);
+// the leave-one-out products come from prefix / suffix passes, so a factor (1 - prob_k) = 0 needs no division
+__global__ __launch_bounds__(256) void occ_blend_bwd_kernel(const float* __restrict__ dists, const int64_t* __restrict__ p2f,
+                                                            const float* __restrict__ grad_images, long n_pix, int K,
+                                                            float sigma, float* __restrict__ grad_dists) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pix) return;
+    const float g = grad_images[p * 4 + 3];
+    // suffix products into the output buffer first, then a forward sweep with the running prefix
+    float suf = 1.0f;
+    for (int k = K - 1; k >= 0; --k) {
+        grad_dists[p * K + k] = suf;
+        const float m = p2f[p * K + k] >= 0 ? 1.0f : 0.0f;
+        suf *= 1.0f - m / (1.0f + expf(dists[p * K + k] / sigma));
+    }
+    float pre = 1.0f;
+    for (int k = 0; k < K; ++k) {
+        const float m = p2f[p * K + k] >= 0 ? 1.0f : 0.0f;
+        const float prob = m / (1.0f + expf(dists[p * K + k] / sigma));
+        // alpha = 1 - prod(q): d alpha / d prob_k = prod_{j != k} q_j ; d prob_k / d d_k = -prob_k (1 - prob_k) / sigma
+        grad_dists[p * K + k] = -g * (pre * grad_dists[p * K + k]) * prob * (1.0f - prob) / sigma * m;
+        pre *= 1.0f - prob;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // device-side auto-reset: pairing (one block) + commit (one block group per pair)
 // ------------------------------------------------------------------------------------------
@@ -2341,6 +2381,23 @@ extern "C" int occ_rasterize_meshes_backward_dists(const float* face_verts, cons
     hipLaunchKernelGGL(occ_rast_naive_bwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, face_verts,
                        pix_to_face, grad_dists, n_meshes, H, W, faces_per_pixel, perspective_correct,
                        clip_barycentric_coords, grad_face_verts);
+    return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
+}
+
+extern "C" int occ_sigmoid_alpha_blend_fwd(const float* dists, const int64_t* pix_to_face, int64_t n_pix, int faces_per_pixel,
+                                           float sigma, float* images, void* stream) {
+    if (!dists || !pix_to_face || !images || n_pix <= 0 || faces_per_pixel <= 0 || !(sigma > 0.f)) return OCC_ERR_ARG;
+    hipLaunchKernelGGL(occ_blend_fwd_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dists,
+                       pix_to_face, (long)n_pix, faces_per_pixel, sigma, images);
+    return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
+}
+
+extern "C" int occ_sigmoid_alpha_blend_bwd(const float* dists, const int64_t* pix_to_face, const float* grad_images,
+                                           int64_t n_pix, int faces_per_pixel, float sigma, float* grad_dists, void* stream) {
+    if (!dists || !pix_to_face || !grad_images || !grad_dists || n_pix <= 0 || faces_per_pixel <= 0 || !(sigma > 0.f))
+        return OCC_ERR_ARG;
+    hipLaunchKernelGGL(occ_blend_bwd_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dists,
+                       pix_to_face, grad_images, (long)n_pix, faces_per_pixel, sigma, grad_dists);
     return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
 }
 

@@ -71,3 +71,41 @@ def rasterize_meshes(face_verts: torch.Tensor, mesh_to_face_first_idx: torch.Ten
     return _RasterizeFaceVerts.apply(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx,
                                      int(H), int(W), blur_radius, int(faces_per_pixel), perspective_correct,
                                      clip_barycentric_coords, cull_backfaces)
+
+
+class _SigmoidAlphaBlend(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dists, pix_to_face, sigma):
+        lib = nat.load()
+        if not dists.is_cuda:
+            raise nat.NativeError("sigmoid_alpha_blend needs CUDA/ROCm tensors; there is no CPU fallback")
+        d = dists.detach().contiguous().float()
+        p2f = pix_to_face.to(d.device, torch.int64).contiguous()
+        K = d.shape[-1]
+        n_pix = d.numel() // K
+        images = torch.empty(d.shape[:-1] + (4,), dtype=torch.float32, device=d.device)
+        st = C.c_void_p(torch.cuda.current_stream(d.device).cuda_stream)
+        nat.check(lib.occ_sigmoid_alpha_blend_fwd(_p(d), _p(p2f), n_pix, K, float(sigma), _p(images), st),
+                  "occ_sigmoid_alpha_blend_fwd")
+        ctx.save_for_backward(d, p2f)
+        ctx.sigma = float(sigma)
+        return images
+
+    @staticmethod
+    def backward(ctx, g_images):
+        d, p2f = ctx.saved_tensors
+        lib = nat.load()
+        K = d.shape[-1]
+        gd = torch.empty_like(d)
+        st = C.c_void_p(torch.cuda.current_stream(d.device).cuda_stream)
+        nat.check(lib.occ_sigmoid_alpha_blend_bwd(_p(d), _p(p2f), _p(g_images.contiguous().float()), d.numel() // K, K,
+                                                  ctx.sigma, _p(gd), st), "occ_sigmoid_alpha_blend_bwd")
+        return gd, None, None
+
+
+def sigmoid_alpha_blend(dists: torch.Tensor, pix_to_face: torch.Tensor, sigma: float = 1e-4) -> torch.Tensor:
+    """PyTorch3D ``sigmoid_alpha_blend`` as ``SoftSilhouetteShader`` applies it (environment.py:242,263): K-buffers
+    ``(N,H,W,K)`` -> RGBA images ``(N,H,W,4)`` with RGB = 1 and alpha = 1 - prod_k (1 - sigmoid(-d_k / sigma) [face >= 0]);
+    differentiable w.r.t. ``dists``.  With ``rasterize_meshes`` this is the reference's silhouette renderer at
+    operator level."""
+    return _SigmoidAlphaBlend.apply(dists, pix_to_face, sigma)

@@ -59,3 +59,35 @@ def test_two_meshes_and_backward(teapot):
         g = x.grad[m * F1:(m + 1) * F1].cpu()
         assert torch.allclose(g, y.grad, atol=1e-4, rtol=1e-3)
         assert float(g[..., 2].abs().max()) == 0.0  # dists do not depend on z
+
+
+def test_sigmoid_alpha_blend_matches_torch_and_oracle(teapot):
+    """rasterize_meshes + sigmoid_alpha_blend = the reference's silhouette renderer at operator level
+    (environment.py:258-264): forward and backward against a plain PyTorch fp32 restatement of the blend on the same
+    K-buffers, and the image against the oracle's soft_silhouette."""
+    from occlusionenv_amd.ops import rasterize_meshes, sigmoid_alpha_blend
+
+    S, K = 48, 100
+    fv, nb = _teapot_scene_face_verts(teapot)
+    F_ = fv.shape[0]
+    x = fv.cuda().requires_grad_(True)
+    p2f, zbuf, bary, dists = rasterize_meshes(x, torch.tensor([0]), torch.tensor([F_]), S, O.BLUR_RADIUS, K, True, True, True)
+    img = sigmoid_alpha_blend(dists, p2f, O.SIGMA)
+    assert img.shape == (1, S, S, 4) and bool((img[..., :3] == 1).all())
+    # plain PyTorch fp32 reference of the same op on the same K-buffers
+    d_ref = dists.detach().clone().requires_grad_(True)
+    prob = torch.sigmoid(-d_ref / O.SIGMA) * (p2f >= 0).float()
+    alpha_ref = 1.0 - torch.prod(1.0 - prob, dim=-1)
+    assert torch.allclose(img[..., 3], alpha_ref, atol=1e-6)
+    w = torch.rand(1, S, S, generator=torch.Generator().manual_seed(1)).cuda()
+    (alpha_ref * w).sum().backward()
+    d_hip = dists.detach().clone().requires_grad_(True)
+    (sigmoid_alpha_blend(d_hip, p2f, O.SIGMA)[..., 3] * w).sum().backward()
+    scale = float(d_ref.grad.abs().max())
+    assert scale > 0 and float((d_hip.grad - d_ref.grad).abs().max()) <= 1e-4 * scale
+    # the whole chain back to the vertices, and the oracle's image of the same mesh
+    (img[..., 3] * w).sum().backward()
+    assert torch.isfinite(x.grad).all() and float(x.grad.abs().max()) > 0
+    r = O._Rasterize.apply(fv, nb, S, float(O.BLUR_RADIUS), K, True, True, True)
+    ora = O.sigmoid_alpha_blend(r[3], r[0])
+    assert torch.allclose(img[0].detach().cpu(), ora, atol=1e-5)
