@@ -630,8 +630,8 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
         }
         const int pos = total + woff + pre;
         // Records of a wave are consecutive (ordered compaction): the survivors put theirs into LDS and the wave
-        // copies the block out with full-width 16-byte stores (a lane writing its own 144-byte record straight to
-        // memory touches nine cache lines that 7 other lanes also write).  Waves with a z-clipped face, or at the
+        // copies the block out with full-width 16-byte stores (a lane writing its own 128-byte record straight to
+        // memory issues eight partial-line stores).  Waves with a z-clipped face, or at the
         // capacity limit, store directly.
         const int wstart = total + woff, nw = __popcll(m1) + __popcll(m2);
         const bool staged = (__ballot(slow) == 0ull) && (wstart + nw <= rec_cap);
@@ -762,7 +762,7 @@ struct Cand {
 // Slot map as in occ_constants.h:
 //   a = x0 y0 z0 x1 | b = y1 z1 x2 y2 | c = z2 id flags inv_area | d = bbox | e = il01 il02 il12 - |
 //   g, h, i = tangents of v0, v1, v2 (dx/del dy/del dx/daz dy/daz)      -- 8 parts = 128 bytes = one cache line
-// The nine float4 parts travel as SSA values (by value, never through a struct in memory: a select between two
+// The eight float4 parts travel as SSA values (by value, never through a struct in memory: a select between two
 // loads of one stack object gets folded into a dynamically indexed load, which pins the object in scratch).
 #define OCC_REC_PARAMS float4 ra, float4 rb, float4 rc, float4 rd, float4 re, float4 rg, float4 rh, float4 ri
 #define OCC_REC_LOAD(src, PARTS)                                                                   \
