@@ -232,7 +232,7 @@ def main():
                          "launches": launches.value,
                          "note": "VALU-bound rasterisation; compulsory bytes are ~1.47 MB/env-step (SURVEY 8d)"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             v, n_s = cpu_baseline(venv, args.cpu_sample, args.img)
             out["cpu_baseline"] = {"value": v, "unit": "env-steps/s", "cores": 1, "kind": "port",
                                    "sample": f"{n_s} env-steps (step + backward) of the same scenes, oracle/ C naive "
