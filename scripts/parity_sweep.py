@@ -1,5 +1,5 @@
 """Randomised parity sweep (GPU box): many seeded scenes through the HIP engine and the CPU oracle.
-    python scripts/parity_sweep.py [n_seeds]     -> one line per case + a summary; exit 1 on a violation."""
+    python scripts/parity_sweep.py [n_seeds [first_seed]]     -> one line per case + a summary; exit 1 on a violation."""
 import os
 import sys
 import time
@@ -12,7 +12,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 worst = {}
 bad = 0
 t0 = time.time()
-for seed in range(100, 100 + n):
+base = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+for seed in range(base, base + n):
     mesh = ("teapot", "synthetic", "mixed", "textured")[seed % 4]
     img = (64, 96, 128)[seed % 3] if mesh != "mixed" else 64
     az = (0.6, 3.0)[seed % 2]
