@@ -1,0 +1,275 @@
+// occ_combine.hpp -- combine / reduce / finish kernels and the host-driven reset hand-off.
+// Part of the single translation unit occ_kernels.hip (included inside namespace occ; not a stand-alone header).
+
+// ------------------------------------------------------------------------------------------
+// combine kernel: one thread per pixel - occlusion image, loss / gradient partials, shading, outputs
+// ------------------------------------------------------------------------------------------
+template <bool SOFT, bool HARD, bool GRAD>
+__global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bpe) {
+    __shared__ float s_red[4][3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int env = blockIdx.x / bpe, blk = blockIdx.x - env * bpe;
+    if (P.sc.skip && P.sc.skip[env]) return;  // outputs of a skipped scene row stay untouched
+    const int S = P.sc.img;
+    const int pix = blk * 256 + tid;
+    const bool live = pix < S * S;
+    const int yi = live ? pix / S : 0, xi = live ? pix - (pix / S) * S : 0;
+    const int tx = xi / OCC_BLOCK, ty = yi / OCC_BLOCK;
+    const int cap = P.sc.rec_cap;
+    float alpha[3] = {0.f, 0.f, 0.f}, dae[3] = {0.f, 0.f, 0.f}, daa[3] = {0.f, 0.f, 0.f};
+    float hz = 3.0e38f;
+    int hrec = -1, hobj = 0;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const int eo = env * 3 + o;
+        ciptr rect = as_const(P.ws.objrect + eo * 4);
+        const bool in = live && as_const(P.ws.nrec + eo)[0] > 0 && tx >= rect[0] && ty >= rect[1] && tx <= rect[2] &&
+                        ty <= rect[3];
+        if (in) {
+            const size_t opix = ((size_t)eo * S + yi) * S + xi;
+            if (SOFT) {
+                alpha[o] = P.ws.obj_alpha[opix];
+                if (GRAD) {
+                    const float2 g = reinterpret_cast<const float2*>(P.ws.obj_grad)[opix];
+                    dae[o] = g.x;
+                    daa[o] = g.y;
+                }
+            }
+            if (HARD) {
+                const float z = P.ws.obj_hz[opix];
+                if (z < hz) {  // strict: on equal depth the earlier object of the joined scene wins
+                    hz = z;
+                    hrec = P.ws.obj_hrec[opix];
+                    hobj = o;
+                }
+            }
+        }
+    }
+    const size_t gp = (size_t)yi * S + xi;
+    if (SOFT) {
+        // environment.py:373: image = i1*i2 + i2*i3 + i1*i3 ; RGB of every silhouette is 1
+        const float I = alpha[0] * alpha[1] + alpha[1] * alpha[2] + alpha[0] * alpha[2];
+        float lsum = live ? I * I : 0.f, ge = 0.f, ga = 0.f;
+        if (GRAD && live) {
+            const float g0 = alpha[1] + alpha[2], g1 = alpha[0] + alpha[2], g2 = alpha[0] + alpha[1];
+            ge = 2.0f * I * (g0 * dae[0] + g1 * dae[1] + g2 * dae[2]);
+            ga = 2.0f * I * (g0 * daa[0] + g1 * daa[1] + g2 * daa[2]);
+        }
+        lsum = wave_sum(lsum);
+        if (GRAD) {
+            ge = wave_sum(ge);
+            ga = wave_sum(ga);
+        }
+        if (lane == 0) {
+            s_red[wave][0] = lsum;
+            s_red[wave][1] = ge;
+            s_red[wave][2] = ga;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float a = 0.f, b = 0.f, c = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                a += s_red[w][0];
+                b += s_red[w][1];
+                c += s_red[w][2];
+            }
+            reinterpret_cast<float4*>(P.ws.partials)[blockIdx.x] = make_float4(a, b, c, 0.f);
+        }
+        if (live) {
+            if (P.out.full_state)
+                reinterpret_cast<float4*>(P.out.full_state)[(size_t)env * S * S + gp] = make_float4(3.f, 3.f, 3.f, I);
+            if (P.out.alphas) {
+                float* __restrict__ al = P.out.alphas + (size_t)env * 3 * S * S + gp;
+                al[0] = alpha[0];
+                al[(size_t)S * S] = alpha[1];
+                al[(size_t)2 * S * S] = alpha[2];
+            }
+        }
+    }
+    if (HARD && live) {
+        // [P3D] HardFlatShader + hard_rgb_blend; depth in channel 3 (environment.py:378)
+        float cr = 1.f, cg = 1.f, cb = 1.f, depth = -1.f;
+        if (hrec >= 0) {
+            const int eo = env * 3 + hobj;
+            const float* __restrict__ r = P.ws.rec + ((size_t)eo * cap + hrec) * OCC_REC_STRIDE;
+            const int fid = __float_as_int(r[R_ID]);
+            const int mesh = P.sc.scene_mesh[eo];
+            const int vo = P.sc.mesh_vert_off[mesh], fo = P.sc.mesh_face_off[mesh];
+            const float ox = P.sc.scene_offset[eo * 3], oy = P.sc.scene_offset[eo * 3 + 1], oz = P.sc.scene_offset[eo * 3 + 2];
+            // per-face shading terms from the setup kernel (flat_shade): one gather instead of face -> 3 vertices
+            const float amb_diff = __uint_as_float(reinterpret_cast<const uint4*>(P.ws.rec_bbox)[(size_t)eo * cap + hrec].w);
+            const float spec = r[R_SPEC];
+            const float* __restrict__ cm = P.cam + (size_t)env * OCC_CAM_STRIDE;
+            // texel: white TexturesVertex interpolated with the (unclipped) barycentrics, or the face's atlas
+            const float fS = (float)S;
+            const float xf = -1.0f + (2.0f * (float)(S - 1 - xi) + 1.0f) / fS;
+            const float yf = -1.0f + (2.0f * (float)(S - 1 - yi) + 1.0f) / fS;
+            const float x0 = r[R_X0], y0 = r[R_Y0], z0 = r[R_Z0], x1 = r[R_X1], y1 = r[R_Y1], z1 = r[R_Z1];
+            const float x2 = r[R_X2], y2 = r[R_Y2], z2 = r[R_Z2];
+            const float ia = r[R_INV_AREA];
+            const float b0 = ((xf - x1) * (y2 - y1) - (yf - y1) * (x2 - x1)) * ia;
+            const float b1 = ((yf - y2) * (x2 - x0) - (xf - x2) * (y2 - y0)) * ia;
+            const float b2 = ((xf - x0) * (y1 - y0) - (yf - y0) * (x1 - x0)) * ia;
+            const float w0 = b0 * z1 * z2, w1 = z0 * b1 * z2, w2 = z0 * z1 * b2;
+            const float den = fmaxf(w0 + w1 + w2, kEpsilon);
+            float q0 = w0 / den, q1 = w1 / den, q2 = w2 / den;
+            float tr = q0 + q1 + q2, tg = tr, tb = tr;
+            const int64_t aoff = P.sc.pool_atlas ? P.sc.mesh_atlas_off[mesh] : -1;
+            if (aoff >= 0) {
+                if (__float_as_int(r[R_FLAGS]) & FLAG_CLIPPED) {
+                    // [P3D] convert_clipped_rasterization_to_original_faces: barycentrics w.r.t. the ORIGINAL face.
+                    // Perspective-correct barycentrics are the 3-D ones: beta_i ~ d . (V_j x V_k) with d the pixel ray
+                    // and V the face's view-space vertices (valid for vertices behind the clip plane too).
+                    float V[3][3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int vi = P.sc.pool_faces[(size_t)(fo + fid) * 3 + k];
+                        const float* pv = P.sc.pool_verts + (size_t)(vo + vi) * 3;
+                        const float wx_ = pv[0] + ox, wy_ = pv[1] + oy, wz_ = pv[2] + oz;
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            V[k][j] = wx_ * cm[C_R + j] + wy_ * cm[C_R + 3 + j] + wz_ * cm[C_R + 6 + j] + cm[C_T + j];
+                    }
+                    const float dx = xf / kProjScale, dy = yf / kProjScale, dz = 1.0f;
+                    auto tri = [&](const float* a, const float* b) {
+                        return dx * (a[1] * b[2] - a[2] * b[1]) + dy * (a[2] * b[0] - a[0] * b[2]) + dz * (a[0] * b[1] - a[1] * b[0]);
+                    };
+                    const float e0 = tri(V[1], V[2]), e1 = tri(V[2], V[0]), e2 = tri(V[0], V[1]);
+                    const float es = e0 + e1 + e2;
+                    q0 = e0 / es; q1 = e1 / es; q2 = e2 / es;
+                }
+                // [P3D] TexturesAtlas.sample_textures: (w0, w1) -> texel of the R x R grid, upper triangle mirrored
+                const int Rr = P.sc.atlas_res;
+                int wx = min((int)(q0 * (float)Rr), Rr - 1), wy = min((int)(q1 * (float)Rr), Rr - 1);
+                const bool below = ((q0 + q1) * (float)Rr - ((float)wx + (float)wy)) <= 1.0f;
+                if (!below) { wx = Rr - 1 - wx; wy = Rr - 1 - wy; }
+                const float* tx = P.sc.pool_atlas + aoff + (((size_t)fid * Rr + wy) * Rr + wx) * 3;
+                tr = tx[0]; tg = tx[1]; tb = tx[2];
+            }
+            cr = amb_diff * tr + spec;
+            cg = amb_diff * tg + spec;
+            cb = amb_diff * tb + spec;
+            depth = hz;
+        }
+        float* __restrict__ ob = P.out.obs + (size_t)env * 4 * S * S + gp;
+        ob[0] = cr;
+        ob[(size_t)S * S] = cg;
+        ob[(size_t)2 * S * S] = cb;
+        ob[(size_t)3 * S * S] = depth;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-env fixed-order reduction of the tile partials
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void occ_reduce_kernel(const float* __restrict__ partials, int ntiles,
+                                                        float* __restrict__ loss, float* __restrict__ grad_elaz,
+                                                        const int* __restrict__ skip) {
+    const int env = blockIdx.x, lane = threadIdx.x;
+    if (skip && skip[env]) return;
+    const float4* __restrict__ p = reinterpret_cast<const float4*>(partials) + (size_t)env * ntiles;
+    float l = 0.f, ge = 0.f, ga = 0.f;
+    for (int t = lane; t < ntiles; t += 64) {
+        const float4 v = p[t];
+        l += v.x;
+        ge += v.y;
+        ga += v.z;
+    }
+    l = wave_sum(l);
+    ge = wave_sum(ge);
+    ga = wave_sum(ga);
+    if (lane == 0) {
+        if (loss) loss[env] = l;
+        if (grad_elaz) {
+            grad_elaz[2 * env] = ge;
+            grad_elaz[2 * env + 1] = ga;
+        }
+    }
+}
+
+// environment.py:381-392 + action Jacobian (:356-361)
+__global__ __launch_bounds__(64) void occ_finish_kernel(const float* __restrict__ loss, const float* __restrict__ grad_elaz,
+                                                        const float* __restrict__ cam, float* __restrict__ full_reward,
+                                                        const float* __restrict__ object_mass, float* __restrict__ reward,
+                                                        uint8_t* __restrict__ done, float* __restrict__ grad_action,
+                                                        int n_env) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_env) return;
+    const float l = loss[n];
+    const float om = object_mass[n];
+    float rw = full_reward[n] - l;
+    full_reward[n] = l;
+    const bool fin = l < kDoneThreshold;
+    rw = rw / om;
+    rw = fin ? rw + kDoneBonus : rw - kStepPenalty;
+    reward[n] = rw;
+    done[n] = fin ? 1 : 0;
+    if (grad_action) {
+        float ga0 = 0.f, ga1 = 0.f;
+        if (grad_elaz) {
+            const float* __restrict__ J = cam + (size_t)n * OCC_CAM_STRIDE + C_J;
+            const float gl_e = grad_elaz[2 * n], gl_a = grad_elaz[2 * n + 1];
+            // d reward/d action_j = -(1/objectMass) * (dL/del * del/da_j + dL/daz * daz/da_j)
+            ga0 = -(gl_e * J[0] + gl_a * J[2]) / om;
+            ga1 = -(gl_e * J[1] + gl_a * J[3]) / om;
+        }
+        grad_action[2 * n] = ga0;
+        grad_action[2 * n + 1] = ga1;
+    }
+}
+
+// One small int32 buffer per step for the host: [0..n) done, [n..n+r) reserve scene passes the reset test
+// (loss > 0.1, environment.py:327), [n+r] any kernel status bit set -> ONE device-to-host copy per step.
+__global__ __launch_bounds__(256) void occ_flags_kernel(const uint8_t* __restrict__ done, const float* __restrict__ loss_all,
+                                                        const int* __restrict__ status, int n, int r,
+                                                        int* __restrict__ flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) flags[n + r] = 0;
+    if (i < n) flags[i] = done[i];
+    else if (i < n + r) flags[i] = loss_all[i] > kDoneThreshold ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void occ_status_any_kernel(const int* __restrict__ status, int nt, int* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nt && status[i] != 0) atomicOr(out, 1);
+}
+
+// Auto-reset commit: env dst[k] takes over reserve row src[k] (all per-env state + the freshly rendered
+// observation) in one launch.  block = one (k, array) pair chunk.
+struct CommitArgs {
+    const int* pairs;  // (n,2): dst env row, src row
+    int n;
+    float* el; float* az; float* radius; float* campos; float* cam; float* alphas; float* full_reward; float* object_mass;
+    int* scene_mesh; float* scene_offset; float* obs; const float* obs_all; const float* loss_all;
+    int img;
+};
+__global__ __launch_bounds__(256) void occ_commit_kernel(CommitArgs a) {
+    const int k = blockIdx.x;
+    const int dst = a.pairs[2 * k], src = a.pairs[2 * k + 1];
+    const int tid = threadIdx.x;
+    const size_t S2 = (size_t)a.img * a.img;
+    if (blockIdx.y == 0) {
+        if (tid == 0) {
+            a.el[dst] = a.el[src];
+            a.az[dst] = a.az[src];
+            a.radius[dst] = a.radius[src];
+            const float l = a.loss_all[src];
+            a.full_reward[dst] = l;
+            a.object_mass[dst] = l + 1.0f;
+        }
+        if (tid < 3) {
+            a.campos[dst * 3 + tid] = 0.f;
+            a.scene_mesh[dst * 3 + tid] = a.scene_mesh[src * 3 + tid];
+        }
+        if (tid < 9) a.scene_offset[dst * 9 + tid] = a.scene_offset[src * 9 + tid];
+        if (tid < OCC_CAM_STRIDE) a.cam[(size_t)dst * OCC_CAM_STRIDE + tid] = a.cam[(size_t)src * OCC_CAM_STRIDE + tid];
+    } else if (blockIdx.y == 1) {
+        const float4* s4 = reinterpret_cast<const float4*>(a.obs_all + (size_t)src * 4 * S2);
+        float4* d4 = reinterpret_cast<float4*>(a.obs + (size_t)dst * 4 * S2);
+        for (size_t i = tid; i < S2; i += 256) d4[i] = s4[i];
+    } else {
+        const float* s1 = a.alphas + (size_t)src * 3 * S2;
+        float* d1 = a.alphas + (size_t)dst * 3 * S2;
+        for (size_t i = tid; i < 3 * S2; i += 256) d1[i] = s1[i];
+    }
+}

@@ -1,0 +1,29 @@
+// occ_common.hpp -- small device helpers shared by every kernel.
+// Part of the single translation unit occ_kernels.hip (included inside namespace occ; not a stand-alone header).
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fmin3(float a, float b, float c) { return fminf(fminf(a, b), c); }
+__device__ __forceinline__ float fmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float clamp01(float t) { return fminf(fmaxf(t, 0.0f), 1.0f); }
+
+// Read-only data produced by an EARLIER launch (face records, bboxes, rects) is read through the
+// constant address space: with a wave-uniform address hipcc then emits s_load_dwordx8/x16 into
+// SGPRs (scalar cache) instead of 64 redundant vector loads.
+typedef const __attribute__((address_space(4))) float* cfptr;
+typedef const __attribute__((address_space(4))) int* ciptr;
+__device__ __forceinline__ cfptr as_const(const float* p) { return (cfptr)(uintptr_t)p; }
+__device__ __forceinline__ ciptr as_const(const int* p) { return (ciptr)(uintptr_t)p; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, 64));
+    return v;
+}

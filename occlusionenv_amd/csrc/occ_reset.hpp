@@ -1,0 +1,180 @@
+// occ_reset.hpp -- device-side auto-reset: stash, pairing, commit, refill.
+// Part of the single translation unit occ_kernels.hip (included inside namespace occ; not a stand-alone header).
+
+// ------------------------------------------------------------------------------------------
+// device-side auto-reset: pairing (one block) + commit (one block group per pair)
+// ------------------------------------------------------------------------------------------
+struct PairArgs {
+    const uint8_t* done; const float* loss_all; const int* status;
+    int n_env, n_res;
+    int* rs_state; int* rs_tries; int* pairs; int* report; int* skip;
+};
+
+// ordered compaction helper: exclusive prefix of flag over a 1024-thread block (16 waves)
+__device__ __forceinline__ int block_prefix_1024(bool flag, int* s_w, int tid, int& total) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const unsigned long long m = __ballot(flag);
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    __syncthreads();  // s_w reuse
+    if (lane == 0) s_w[wave] = __popcll(m);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int v = s_w[w];
+        if (w < wave) off += v;
+        tot += v;
+    }
+    total = tot;
+    return off + __popcll(m & lt);
+}
+
+__global__ __launch_bounds__(1024) void occ_pair_kernel(PairArgs a) {
+    __shared__ int s_w[16];
+    __shared__ int s_fin[512], s_ready[512];
+    __shared__ int s_any;
+    const int tid = threadIdx.x;
+    const int N = a.n_env, R = a.n_res;
+    if (tid == 0) s_any = 0;
+    // (1) age the PENDING slots: every slot was rendered by this step's launch with its current scene
+    int st = OCC_RS_EMPTY;
+    if (tid < R) {
+        st = a.rs_state[tid];
+        if (st == OCC_RS_PENDING) {
+            const int t = a.rs_tries[tid] + 1;
+            // accept, or keep the 10th try regardless (environment.py:288,327)
+            st = (a.loss_all[N + tid] > kDoneThreshold || t >= 10) ? OCC_RS_READY : OCC_RS_EMPTY;
+            a.rs_tries[tid] = t;
+        }
+        a.report[N + R + tid] = -1;
+    }
+    int nready;
+    const int rpos = block_prefix_1024(tid < R && st == OCC_RS_READY, s_w, tid, nready);
+    if (tid < R && st == OCC_RS_READY) s_ready[rpos] = tid;
+    // (2) finished envs in index order (the first 512 are kept: no more slots than that exist)
+    int nfin = 0, any = 0;
+    for (int base = 0; base < N; base += 1024) {
+        const int i = base + tid;
+        const bool f = i < N && a.done[i] != 0;
+        if (i < N) {
+            a.report[i] = f ? 1 : 0;
+            any |= a.status[i];
+        }
+        int tot;
+        const int pos = nfin + block_prefix_1024(f, s_w, tid, tot);
+        if (f && pos < 512) s_fin[pos] = i;
+        nfin += tot;
+    }
+    if (tid < R) any |= a.status[N + tid];
+    if (any) atomicOr(&s_any, 1);
+    __syncthreads();
+    // (3) pair them
+    const int npair = min(min(nfin, nready), R);
+    if (tid < npair) {
+        const int r = s_ready[tid], i = s_fin[tid];
+        a.pairs[2 + 2 * tid] = i;
+        a.pairs[3 + 2 * tid] = N + r;
+        a.report[N + R + r] = i;
+    }
+    // a READY slot that was taken goes back to EMPTY with a fresh try count
+    const bool taken = tid < R && st == OCC_RS_READY && rpos < npair;
+    if (tid < R) {
+        if (taken) {
+            st = OCC_RS_EMPTY;
+            a.rs_tries[tid] = 0;
+        }
+        a.rs_state[tid] = st;
+        a.report[N + tid] = st;
+        a.skip[N + tid] = (st != OCC_RS_PENDING) ? 1 : 0;  // only slots under test are rendered by the next step
+    }
+    if (tid == 0) {
+        a.pairs[0] = npair;
+        a.report[N + 2 * R] = s_any;
+        a.report[N + 2 * R + 1] = nfin - npair;
+    }
+}
+
+// rows this step rendered for PENDING slots -> persistent store (runs BEFORE the pairing changes any state)
+struct StashArgs {
+    const int* rs_state; const float* obs_all; const float* fs_all; const float* loss_all;
+    OccReserveStore store;
+    int img, n_env;
+};
+constexpr int kStashBlocks = 16;
+__global__ __launch_bounds__(256) void occ_stash_kernel(StashArgs a) {
+    const int r = blockIdx.x;
+    if (a.rs_state[r] != OCC_RS_PENDING) return;
+    const int tid = threadIdx.x, y = blockIdx.y;
+    const size_t S2 = (size_t)a.img * a.img, src = (size_t)(a.n_env + r);
+    const float4* o4 = reinterpret_cast<const float4*>(a.obs_all + src * 4 * S2);
+    const float4* f4 = reinterpret_cast<const float4*>(a.fs_all + src * 4 * S2);
+    float4* od = reinterpret_cast<float4*>(a.store.obs + (size_t)r * 4 * S2);
+    float4* fd = reinterpret_cast<float4*>(a.store.full_state + (size_t)r * 4 * S2);
+    for (size_t i = (size_t)y * 256 + tid; i < S2; i += (size_t)kStashBlocks * 256) {
+        od[i] = o4[i];
+        fd[i] = f4[i];
+    }
+    if (y == 0 && tid == 0) a.store.loss[r] = a.loss_all[src];
+}
+
+struct AutoCommitArgs {
+    const int* pairs;
+    OccEnvState st;
+    float* obs_all; float* term_obs; const float* res_obs; const float* res_loss;
+    int img, n_env;
+};
+constexpr int kCommitObsBlocks = 8, kCommitAlphaBlocks = 6;
+__global__ __launch_bounds__(256) void occ_auto_commit_kernel(AutoCommitArgs a) {
+    const int k = blockIdx.x;
+    if (k >= a.pairs[0]) return;
+    const int dst = a.pairs[2 + 2 * k], src = a.pairs[3 + 2 * k];
+    const int tid = threadIdx.x, y = blockIdx.y;
+    const size_t S2 = (size_t)a.img * a.img;
+    if (y == 0) {
+        if (tid == 0) {
+            a.st.el[dst] = a.st.el[src];
+            a.st.az[dst] = a.st.az[src];
+            a.st.radius[dst] = a.st.radius[src];
+            const float l = a.res_loss[src - a.n_env];
+            a.st.full_reward[dst] = l;
+            a.st.object_mass[dst] = l + 1.0f;
+        }
+        if (tid < 3) {
+            a.st.campos[dst * 3 + tid] = 0.f;
+            a.st.scene_mesh[dst * 3 + tid] = a.st.scene_mesh[src * 3 + tid];
+        }
+        if (tid < 9) a.st.scene_offset[dst * 9 + tid] = a.st.scene_offset[src * 9 + tid];
+        if (tid < OCC_CAM_STRIDE) a.st.cam[(size_t)dst * OCC_CAM_STRIDE + tid] = a.st.cam[(size_t)src * OCC_CAM_STRIDE + tid];
+    } else if (y <= kCommitObsBlocks) {
+        // final observation -> term_obs[slot], stored reset observation -> obs[env] (same element range, same thread)
+        const float4* s4 = reinterpret_cast<const float4*>(a.res_obs + (size_t)(src - a.n_env) * 4 * S2);
+        float4* d4 = reinterpret_cast<float4*>(a.obs_all + (size_t)dst * 4 * S2);
+        float4* t4 = reinterpret_cast<float4*>(a.term_obs + (size_t)(src - a.n_env) * 4 * S2);
+        for (size_t i = (size_t)(y - 1) * 256 + tid; i < S2; i += (size_t)kCommitObsBlocks * 256) {
+            t4[i] = d4[i];
+            d4[i] = s4[i];
+        }
+    } else {
+        const float* s1 = a.st.alphas + (size_t)src * 3 * S2;
+        float* d1 = a.st.alphas + (size_t)dst * 3 * S2;
+        for (size_t i = (size_t)(y - 1 - kCommitObsBlocks) * 256 + tid; i < 3 * S2; i += (size_t)kCommitAlphaBlocks * 256)
+            d1[i] = s1[i];
+    }
+}
+
+__global__ __launch_bounds__(64) void occ_refill_kernel(const int* __restrict__ packed, int n, int n_env, int n_res,
+                                                        int* __restrict__ scene_mesh, float* __restrict__ scene_offset,
+                                                        int* __restrict__ rs_state, int* __restrict__ skip) {
+    const int k = blockIdx.x, tid = threadIdx.x;
+    if (k >= n) return;
+    const int* row = packed + 13 * k;
+    const int slot = row[0];
+    if (slot < 0 || slot >= n_res) return;
+    const int e = n_env + slot;
+    if (tid < 3) scene_mesh[e * 3 + tid] = row[1 + tid];
+    if (tid < 9) scene_offset[e * 9 + tid] = __int_as_float(row[4 + tid]);
+    if (tid == 0) {
+        rs_state[slot] = OCC_RS_PENDING;
+        skip[e] = 0;  // rendered from the next launch on
+    }
+}

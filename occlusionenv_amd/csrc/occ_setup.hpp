@@ -1,0 +1,541 @@
+// occ_setup.hpp -- setup + sort kernels: projection, z-clipping, culling, face records, scan rows.
+// Part of the single translation unit occ_kernels.hip (included inside namespace occ; not a stand-alone header).
+
+// ------------------------------------------------------------------------------------------
+// setup: projection, z-clipping, culling, record build with ordered compaction
+// ------------------------------------------------------------------------------------------
+struct PVert {      // one projected vertex
+    float x, y, z;  // x_ndc, y_ndc, z_view
+    float t[4];     // d x/d el, d y/d el, d x/d az, d y/d az
+};
+
+struct VVert {  // view-space vertex with tangents
+    float v[3];
+    float de[3], da[3];
+};
+
+template <bool GRAD>
+__device__ __forceinline__ PVert project(const VVert& q) {
+    // [P3D] x_ndc = x_view * s / z_view  
+    PVert p;
+    const float iz = 1.0f / q.v[2];
+    p.x = q.v[0] * kProjScale * iz;
+    p.y = q.v[1] * kProjScale * iz;
+    p.z = q.v[2];
+    if (GRAD) {
+        p.t[0] = (kProjScale * q.de[0] - p.x * q.de[2]) * iz;
+        p.t[1] = (kProjScale * q.de[1] - p.y * q.de[2]) * iz;
+        p.t[2] = (kProjScale * q.da[0] - p.x * q.da[2]) * iz;
+        p.t[3] = (kProjScale * q.da[1] - p.y * q.da[2]) * iz;
+    } else {
+        p.t[0] = p.t[1] = p.t[2] = p.t[3] = 0.f;
+    }
+    return p;
+}
+
+// [P3D] clip_faces: intersection of edge (a -> b) with z = kZClip, weight detached
+template <bool GRAD>
+__device__ __forceinline__ PVert cut_edge(const VVert& a, const VVert& b) {
+    PVert p;
+    const float w = (a.v[2] - kZClip) / (a.v[2] - b.v[2]);
+    const float iw = 1.0f - w;
+    const float ic = 1.0f / kZClip;
+    p.z = a.v[2] * iw + b.v[2] * w;
+    p.x = (kProjScale * a.v[0] * iw + kProjScale * b.v[0] * w) * ic;
+    p.y = (kProjScale * a.v[1] * iw + kProjScale * b.v[1] * w) * ic;
+    if (GRAD) {
+        p.t[0] = (kProjScale * a.de[0] * iw + kProjScale * b.de[0] * w) * ic;
+        p.t[1] = (kProjScale * a.de[1] * iw + kProjScale * b.de[1] * w) * ic;
+        p.t[2] = (kProjScale * a.da[0] * iw + kProjScale * b.da[0] * w) * ic;
+        p.t[3] = (kProjScale * a.da[1] * iw + kProjScale * b.da[1] * w) * ic;
+    } else {
+        p.t[0] = p.t[1] = p.t[2] = p.t[3] = 0.f;
+    }
+    return p;
+}
+
+struct Tri {
+    PVert v[3];
+    uint4 bbox;  // conservative pixel bbox x = xl | yl << 16, y = xh | yh << 16; z = key of the smallest vertex depth
+    int tx0, ty0, tx1, ty1;
+};
+
+// Returns false if the triangle can never be matched to a pixel (culled / degenerate / off screen).  EVERY field
+// is filled with in-range values either way: occ_setup_kernel evaluates a surviving face twice (once to count it,
+// once to write it) and the two inlined copies need not round alike (fp contraction), so the second evaluation
+// must be safe to use even where it would, by a hair, have decided differently.
+__device__ __forceinline__ bool finish_tri(Tri& t, int S) {
+    const float x0 = t.v[0].x, y0 = t.v[0].y, x1 = t.v[1].x, y1 = t.v[1].y, x2 = t.v[2].x, y2 = t.v[2].y;
+    // [P3D] face_area = EdgeFunction(v0; v1, v2); back faces are culled (environment.py:253,271)
+    const float area = (x0 - x1) * (y2 - y1) - (y0 - y1) * (x2 - x1);
+    bool vis = area > kEpsilon;  // false for a back face, zero area or NaN
+    vis = vis && !(fmax3(t.v[0].z, t.v[1].z, t.v[2].z) < 0.0f);
+    const float bx0 = fmin3(x0, x1, x2) - kSqrtBlur, bx1 = fmax3(x0, x1, x2) + kSqrtBlur;
+    const float by0 = fmin3(y0, y1, y2) - kSqrtBlur, by1 = fmax3(y0, y1, y2) + kSqrtBlur;
+    const float lim = 1.0f - 1.0f / (float)S;  // outermost pixel centre
+    vis = vis && !(bx1 < -lim || bx0 > lim || by1 < -lim || by0 > lim);
+    // pixel index of an NDC coordinate: u(f) = (S-1) - ((f+1)*S - 1)/2   (decreasing)
+    const float fS = (float)S;
+    auto u = [&](float f) { return (fS - 1.0f) - ((f + 1.0f) * fS - 1.0f) * 0.5f; };
+    // pixels whose centre can pass the exact float test bx0 <= xf <= bx1 (u is decreasing); 1e-3 px of slack
+    // covers the rounding of u() - the per-pixel float test in eval_face stays the authority
+    int xl = (int)ceilf(u(bx1) - 1e-3f), xh = (int)floorf(u(bx0) + 1e-3f);
+    int yl = (int)ceilf(u(by1) - 1e-3f), yh = (int)floorf(u(by0) + 1e-3f);
+    vis = vis && (max(xl, 0) <= min(xh, S - 1)) && (max(yl, 0) <= min(yh, S - 1));
+    xl = min(max(xl, 0), S - 1);
+    yl = min(max(yl, 0), S - 1);
+    xh = min(max(xh, xl), S - 1);
+    yh = min(max(yh, yl), S - 1);
+    t.tx0 = xl / OCC_BLOCK;
+    t.tx1 = xh / OCC_BLOCK;
+    t.ty0 = yl / OCC_BLOCK;
+    t.ty1 = yh / OCC_BLOCK;
+    const uint32_t zb = __float_as_uint(fmin3(t.v[0].z, t.v[1].z, t.v[2].z));
+    t.bbox = make_uint4((uint32_t)xl | ((uint32_t)yl << 16), (uint32_t)xh | ((uint32_t)yh << 16),
+                        (zb & 0x80000000u) ? ~zb : (zb | 0x80000000u), 0u);
+    return vis;
+}
+
+// [P3D] HardFlatShader terms of ONE face: flat shading uses the face normal and the face centre only,
+// so (ambient + diffuse) and the specular term are per-face constants of the current camera.  w0..w2 = the
+// ORIGINAL face's world-space corners (also for z-clipped pieces), cpos = camera centre.  Computed once per
+// visible face by the setup kernel; the combine kernel then shades a pixel with one gather.
+struct Shade {
+    float amb_diff, spec;
+};
+__device__ __forceinline__ Shade flat_shade(const float* w0, const float* w1, const float* w2, float cx, float cy, float cz) {
+    // hardware sqrt / rcp (1 ulp) instead of the IEEE sequences: ~1e-7 relative on a colour in [0.5, 1]
+    auto inv_len = [](float x, float y, float z) { return frcp(fmaxf(__builtin_amdgcn_sqrtf(x * x + y * y + z * z), kShadeEps)); };
+    const float ax = w1[0] - w0[0], ay = w1[1] - w0[1], az = w1[2] - w0[2];
+    const float bx = w2[0] - w0[0], by = w2[1] - w0[1], bz = w2[2] - w0[2];
+    float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+    float in_ = inv_len(nx, ny, nz);
+    nx *= in_; ny *= in_; nz *= in_;
+    in_ = inv_len(nx, ny, nz);  // F.normalize again in diffuse()/specular()
+    nx *= in_; ny *= in_; nz *= in_;
+    const float third = 1.0f / 3.0f;
+    const float ccx = (w0[0] + w1[0] + w2[0]) * third, ccy = (w0[1] + w1[1] + w2[1]) * third,
+                ccz = (w0[2] + w1[2] + w2[2]) * third;
+    float lx = kLightX - ccx, ly = kLightY - ccy, lz = kLightZ - ccz;
+    const float il = inv_len(lx, ly, lz);
+    lx *= il; ly *= il; lz *= il;
+    const float cosang = nx * lx + ny * ly + nz * lz;
+    const float diffuse = kDiffuse * fmaxf(cosang, 0.f);
+    float vx = cx - ccx, vy = cy - ccy, vz = cz - ccz;
+    const float iv = inv_len(vx, vy, vz);
+    vx *= iv; vy *= iv; vz *= iv;
+    const float rx = -lx + 2.f * (cosang * nx), ry = -ly + 2.f * (cosang * ny), rz = -lz + 2.f * (cosang * nz);
+    float sa = fmaxf(vx * rx + vy * ry + vz * rz, 0.f) * (cosang > 0.f ? 1.f : 0.f);
+    sa *= sa; sa *= sa; sa *= sa; sa *= sa; sa *= sa; sa *= sa;  // ^64
+    Shade sh;
+    sh.amb_diff = kAmbient + diffuse;
+    sh.spec = kSpecular * sa;
+    return sh;
+}
+
+template <bool GRAD>
+__device__ __forceinline__ void write_record(float* __restrict__ r, uint4* __restrict__ bb, uint4* __restrict__ scan_row,
+                                             int pos, const Tri& t, int face_id, int flags, Shade sh) {
+    const float x0 = t.v[0].x, y0 = t.v[0].y, x1 = t.v[1].x, y1 = t.v[1].y, x2 = t.v[2].x, y2 = t.v[2].y;
+    // [P3D] BarycentricCoordsForward: area = EdgeFunction(v2; v0, v1) + kEpsilon
+    const float area = (x2 - x0) * (y1 - y0) - (y2 - y0) * (x1 - x0) + kEpsilon;
+    const float l01 = (x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0);
+    const float l02 = (x2 - x0) * (x2 - x0) + (y2 - y0) * (y2 - y0);
+    const float l12 = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1);
+    float4* r4 = reinterpret_cast<float4*>(r);
+    // slot map: occ_constants.h (R_X0 .. R_TAN)
+    r4[0] = make_float4(x0, y0, t.v[0].z, x1);
+    r4[1] = make_float4(y1, t.v[1].z, x2, y2);
+    r4[2] = make_float4(t.v[2].z, __int_as_float(face_id), __int_as_float(flags), 1.0f / area);
+    r4[3] = make_float4(fmin3(x0, x1, x2) - kSqrtBlur, fmax3(x0, x1, x2) + kSqrtBlur, fmin3(y0, y1, y2) - kSqrtBlur,
+                        fmax3(y0, y1, y2) + kSqrtBlur);
+    r4[4] = make_float4(l01 <= kEpsilon ? -1.0f : 1.0f / l01, l02 <= kEpsilon ? -1.0f : 1.0f / l02,
+                        l12 <= kEpsilon ? -1.0f : 1.0f / l12, sh.spec);
+    if (GRAD) {
+        r4[5] = make_float4(t.v[0].t[0], t.v[0].t[1], t.v[0].t[2], t.v[0].t[3]);
+        r4[6] = make_float4(t.v[1].t[0], t.v[1].t[1], t.v[1].t[2], t.v[1].t[3]);
+        r4[7] = make_float4(t.v[2].t[0], t.v[2].t[1], t.v[2].t[2], t.v[2].t[3]);
+    }
+    *bb = make_uint4(t.bbox.x, t.bbox.y, t.bbox.z, __float_as_uint(sh.amb_diff));  // .w: ambient + diffuse of the face
+    // scan row in face order (occ_sort_kernel re-orders dense objects): (pixel bbox, nearest depth key, record index)
+    *scan_row = make_uint4(t.bbox.x, t.bbox.y, t.bbox.z, (uint32_t)pos);
+}
+
+// union pixel bbox and smallest depth key of every 64-entry chunk of the scan order (two-level scan)
+__device__ __forceinline__ void chunk_boxes(const uint4* __restrict__ scan, uint4* __restrict__ cbx, int nr, int wave,
+                                            int lane) {
+    const int nch = (nr + 63) >> 6;
+    for (int c = wave; c < nch; c += 4) {
+        const int j = c * 64 + lane;
+        uint4 bb = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
+        if (j < nr) bb = scan[j];
+        int xl = bb.x & 0xFFFF, yl = bb.x >> 16, xh = bb.y & 0xFFFF, yh = bb.y >> 16;
+        uint32_t zk = bb.z;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            xl = min(xl, __shfl_xor(xl, m, 64));
+            yl = min(yl, __shfl_xor(yl, m, 64));
+            xh = max(xh, __shfl_xor(xh, m, 64));
+            yh = max(yh, __shfl_xor(yh, m, 64));
+            zk = min(zk, (uint32_t)__shfl_xor((int)zk, m, 64));
+        }
+        if (lane == 0)
+            cbx[c] = make_uint4((uint32_t)xl | ((uint32_t)yl << 16), (uint32_t)xh | ((uint32_t)yh << 16), zk, 0u);
+    }
+}
+
+// Objects with many visible faces (>= kSortMin records: a pixel then collects far more than K candidates) get
+// their scan order sorted front to back - bitonic sort of (depth key, record index) in LDS - so that the raster
+// kernel reaches "every pixel of the block holds its K nearest" after the nearest faces and skips the rest.
+constexpr int kSortMin = 4096;
+__global__ __launch_bounds__(256) void occ_sort_kernel(OccScene sc, OccWorkspace ws, int sort_cap) {
+    extern __shared__ unsigned long long s_keys[];  // sort_cap keys: depth key << 32 | record index
+    const int eo = blockIdx.x;
+    const int nr = ws.nrec[eo];
+    if (nr < kSortMin) return;
+    int p2 = 1;
+    while (p2 < nr) p2 <<= 1;
+    if (p2 > sort_cap) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint4* __restrict__ bbs = reinterpret_cast<const uint4*>(ws.rec_bbox) + (size_t)eo * sc.rec_cap;
+    uint4* __restrict__ scan = reinterpret_cast<uint4*>(ws.scan) + (size_t)eo * sc.rec_cap;
+    for (int i = tid; i < p2; i += 256) s_keys[i] = i < nr ? (((unsigned long long)bbs[i].z << 32) | (unsigned)i) : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= p2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < p2; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = s_keys[i], b = s_keys[ixj];
+                    const bool asc = (i & k) == 0;
+                    if ((a > b) == asc) {
+                        s_keys[i] = b;
+                        s_keys[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < nr; i += 256) {
+        const int j = (int)(s_keys[i] & 0xFFFFFFFFu);
+        const uint4 bb = bbs[j];
+        scan[i] = make_uint4(bb.x, bb.y, bb.z, (uint32_t)j);
+    }
+    __syncthreads();
+    chunk_boxes(scan, reinterpret_cast<uint4*>(ws.rec_cbox) + (size_t)eo * ((sc.rec_cap + 63) >> 6), nr, wave, lane);
+}
+
+struct CamRT {
+    float R[9], T[3], dRe[9], dTe[3], dRa[9], dTa[3];
+};
+
+// world-space vertex k of face f: pool vertex + object offset in f32 (environment.py:148,171)
+__device__ __forceinline__ void world_vertex(const int* __restrict__ pool_faces, const float* __restrict__ pool_verts,
+                                             int vo, int fo, int f, int k, float ox, float oy, float oz, float* w) {
+    const int vi = pool_faces[(size_t)(fo + f) * 3 + k];
+    const float* pv = pool_verts + (size_t)(vo + vi) * 3;
+    w[0] = pv[0] + ox;
+    w[1] = pv[1] + oy;
+    w[2] = pv[2] + oz;
+}
+
+__device__ __forceinline__ void world_corner(const float* __restrict__ pool_verts, int vo, int vi, float ox, float oy,
+                                             float oz, float* w) {
+    const float* pv = pool_verts + (size_t)(vo + vi) * 3;
+    w[0] = pv[0] + ox;
+    w[1] = pv[1] + oy;
+    w[2] = pv[2] + oz;
+}
+
+template <bool GRAD>
+__device__ __forceinline__ void view_from_world(const CamRT& c, const float* w, VVert& q) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        q.v[j] = w[0] * c.R[j] + w[1] * c.R[3 + j] + w[2] * c.R[6 + j] + c.T[j];
+        if (GRAD) {
+            q.de[j] = w[0] * c.dRe[j] + w[1] * c.dRe[3 + j] + w[2] * c.dRe[6 + j] + c.dTe[j];
+            q.da[j] = w[0] * c.dRa[j] + w[1] * c.dRa[3 + j] + w[2] * c.dRa[6 + j] + c.dTa[j];
+        }
+    }
+}
+
+template <bool GRAD>
+__device__ __forceinline__ void load_camera(const float* __restrict__ c, CamRT& C) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        C.R[i] = c[C_R + i];
+        C.dRe[i] = GRAD ? c[C_DR_EL + i] : 0.f;
+        C.dRa[i] = GRAD ? c[C_DR_AZ + i] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        C.T[i] = c[C_T + i];
+        C.dTe[i] = GRAD ? c[C_DT_EL + i] : 0.f;
+        C.dTa[i] = GRAD ? c[C_DT_AZ + i] : 0.f;
+    }
+}
+
+// Faces that straddle z = kZClip ([P3D] clip_faces cases 3 and 4).  Rare (the camera must be within
+// ~0.5 of the geometry), so this lives out of line: it re-derives everything from the face index, both when the
+// face is counted and when its records are written, and keeps its dynamically indexed arrays off the hot path.
+// Everything arrives by value (the camera is re-read from memory) so that nothing of the caller's state has its
+// address taken - that would pin the kernel arguments and the camera in scratch for the fast path as well.
+template <bool GRAD>
+__device__ __attribute__((noinline)) int clip_face_slow(const int* __restrict__ pool_faces, const float* __restrict__ pool_verts,
+                                                        const float* __restrict__ camp, int S, int vo, int fo, int f,
+                                                        float ox, float oy, float oz, Tri* out, int* flags) {
+    CamRT c;
+    load_camera<GRAD>(camp, c);
+    VVert q[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float w[3];
+        world_vertex(pool_faces, pool_verts, vo, fo, f, k, ox, oy, oz, w);
+        view_from_world<GRAD>(c, w, q[k]);
+    }
+    const bool b0 = q[0].v[2] < kZClip, b1 = q[1].v[2] < kZClip, b2 = q[2].v[2] < kZClip;
+    const int nb = (int)b0 + (int)b1 + (int)b2;
+    flags[0] = flags[1] = FLAG_CLIPPED;
+    if (nb == 2) {
+        // case 3: p1 = the vertex in front; new triangle (p4, p5, p1)
+        const int i1 = !b0 ? 0 : (!b1 ? 1 : 2);
+        const int i2 = (i1 + 1) % 3, i3 = (i1 + 2) % 3;
+        out[0].v[0] = cut_edge<GRAD>(q[i1], q[i2]);
+        out[0].v[1] = cut_edge<GRAD>(q[i1], q[i3]);
+        out[0].v[2] = project<GRAD>(q[i1]);
+        return finish_tri(out[0], S) ? 1 : 0;
+    }
+    if (nb == 1) {
+        // case 4: p1 = the vertex behind; quad -> (p4, p2, p5), (p5, p2, p3)
+        const int i1 = b0 ? 0 : (b1 ? 1 : 2);
+        const int i2 = (i1 + 1) % 3, i3 = (i1 + 2) % 3;
+        const PVert p4 = cut_edge<GRAD>(q[i1], q[i2]);
+        const PVert p5 = cut_edge<GRAD>(q[i1], q[i3]);
+        const PVert p2 = project<GRAD>(q[i2]);
+        const PVert p3 = project<GRAD>(q[i3]);
+        Tri ta, tb;
+        ta.v[0] = p4; ta.v[1] = p2; ta.v[2] = p5;
+        tb.v[0] = p5; tb.v[1] = p2; tb.v[2] = p3;
+        const bool oka = finish_tri(ta, S), okb = finish_tri(tb, S);
+        if (oka && okb) {
+            out[0] = ta; out[1] = tb;
+            flags[0] = FLAG_PAIR_FIRST | FLAG_CLIPPED; flags[1] = FLAG_PAIR_SECOND | FLAG_CLIPPED;
+            return 2;
+        }
+        if (oka) { out[0] = ta; return 1; }
+        if (okb) { out[0] = tb; return 1; }
+    }
+    return 0;  // nb == 3: the whole face is behind the clip plane
+}
+
+template <bool GRAD>
+__global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const float* __restrict__ cam, OccWorkspace ws) {
+    __shared__ int s_wcnt[2][4];  // double-buffered: one barrier per 256-face round
+    __shared__ int s_rect[4];
+    __shared__ float4 s_rec[4 * 64 * kRecPad];  // per wave: the records of one round, staged for coalesced stores
+    // (LDS stride 9 parts = 36 dwords: a 32-dword stride would put every lane's write on the same banks)
+    const int eo = blockIdx.x;  // env*3 + object
+    const int env = eo / 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (sc.skip && sc.skip[env]) {  // scene row not rendered in this launch: no records, no work items
+        if (tid == 0) {
+            ws.nrec[eo] = 0;
+            ws.objrect[eo * 4 + 0] = 1 << 20;
+            ws.objrect[eo * 4 + 1] = 1 << 20;
+            ws.objrect[eo * 4 + 2] = -1;
+            ws.objrect[eo * 4 + 3] = -1;
+        }
+        return;
+    }
+    const int mesh = sc.scene_mesh[eo];
+    const int vo = sc.mesh_vert_off[mesh];
+    const int fo = sc.mesh_face_off[mesh];
+    const int nF = sc.mesh_face_off[mesh + 1] - fo;
+    const float ox = sc.scene_offset[eo * 3], oy = sc.scene_offset[eo * 3 + 1], oz = sc.scene_offset[eo * 3 + 2];
+    const float* __restrict__ c = cam + (size_t)env * OCC_CAM_STRIDE;
+    CamRT C;
+    load_camera<GRAD>(c, C);
+    const int* __restrict__ pool_faces = sc.pool_faces;
+    const float* __restrict__ pool_verts = sc.pool_verts;
+    const int S = sc.img, rec_cap = sc.rec_cap;
+    if (tid == 0) {
+        s_rect[0] = 1 << 20;
+        s_rect[1] = 1 << 20;
+        s_rect[2] = -1;
+        s_rect[3] = -1;
+    }
+    __syncthreads();
+    float* __restrict__ rec = ws.rec + (size_t)eo * rec_cap * OCC_REC_STRIDE;
+    uint4* __restrict__ bbs = reinterpret_cast<uint4*>(ws.rec_bbox) + (size_t)eo * rec_cap;
+    uint4* __restrict__ scan = reinterpret_cast<uint4*>(ws.scan) + (size_t)eo * rec_cap;
+    int total = 0;
+    bool overflow = false;
+    int rx0 = 1 << 20, ry0 = 1 << 20, rx1 = -1, ry1 = -1;  // this thread's share of the object's block rect
+    int round = 0;
+    // vertex indices of the NEXT round's face are fetched one round ahead: the index -> vertex -> projection chain
+    // of a round then starts at the vertex gather
+    int vi0 = 0, vi1 = 0, vi2 = 0;
+    if (tid < nF) {
+        const int* pf = pool_faces + (size_t)(fo + tid) * 3;
+        vi0 = pf[0]; vi1 = pf[1]; vi2 = pf[2];
+    }
+    for (int base = 0; base < nF; base += 256, round ^= 1) {
+        const int f = base + tid;
+        int cnt = 0;
+        bool slow = false;
+        float w0[3], w1[3], w2[3];  // world-space corners: all that a surviving face carries across the barrier
+        const int c0 = vi0, c1 = vi1, c2 = vi2;
+        if (f + 256 < nF) {
+            const int* pf = pool_faces + (size_t)(fo + f + 256) * 3;
+            vi0 = pf[0]; vi1 = pf[1]; vi2 = pf[2];
+        }
+        if (f < nF) {
+            Tri tri;  // fast path: the unclipped face, positions only (recomputed for the survivors below)
+            VVert q0, q1, q2;
+            world_corner(pool_verts, vo, c0, ox, oy, oz, w0);
+            world_corner(pool_verts, vo, c1, ox, oy, oz, w1);
+            world_corner(pool_verts, vo, c2, ox, oy, oz, w2);
+            view_from_world<false>(C, w0, q0);
+            view_from_world<false>(C, w1, q1);
+            view_from_world<false>(C, w2, q2);
+            slow = (q0.v[2] < kZClip) || (q1.v[2] < kZClip) || (q2.v[2] < kZClip);
+            if (!slow) {
+                tri.v[0] = project<false>(q0);
+                tri.v[1] = project<false>(q1);
+                tri.v[2] = project<false>(q2);
+                cnt = finish_tri(tri, S) ? 1 : 0;
+            }
+        }
+        if (__ballot(slow)) {
+            if (slow) {
+                Tri tmp[2];
+                int fl[2];
+                cnt = clip_face_slow<GRAD>(pool_faces, pool_verts, c, S, vo, fo, f, ox, oy, oz, tmp, fl);
+            }
+        }
+        // ordered compaction: exclusive prefix of cnt in {0,1,2} over the block
+        const unsigned long long m1 = __ballot(cnt >= 1), m2 = __ballot(cnt == 2);
+        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const int pre = __popcll(m1 & lt) + __popcll(m2 & lt);
+        if (lane == 0) s_wcnt[round][wave] = __popcll(m1) + __popcll(m2);
+        __syncthreads();
+        int woff = 0, itot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int cw = s_wcnt[round][w];
+            if (w < wave) woff += cw;
+            itot += cw;
+        }
+        const int pos = total + woff + pre;
+        // Records of a wave are consecutive (ordered compaction): the survivors put theirs into LDS and the wave
+        // copies the block out with full-width 16-byte stores (a lane writing its own 128-byte record straight to
+        // memory issues eight partial-line stores).  Waves with a z-clipped face, or at the
+        // capacity limit, store directly.
+        const int wstart = total + woff, nw = __popcll(m1) + __popcll(m2);
+        const bool staged = (__ballot(slow) == 0ull) && (wstart + nw <= rec_cap);
+        if (cnt >= 1) {
+            if (pos + cnt <= rec_cap) {
+                int x0, y0, x1, y1;
+                const Shade sh = flat_shade(w0, w1, w2, c[C_C], c[C_C + 1], c[C_C + 2]);
+                if (!slow) {
+                    Tri tri;
+                    {
+                        VVert q;
+                        view_from_world<false>(C, w0, q);
+                        tri.v[0] = project<false>(q);
+                        view_from_world<false>(C, w1, q);
+                        tri.v[1] = project<false>(q);
+                        view_from_world<false>(C, w2, q);
+                        tri.v[2] = project<false>(q);
+                        finish_tri(tri, S);
+                    }
+                    auto emit = [&](float* __restrict__ r) {
+                        write_record<false>(r, bbs + pos, scan + pos, pos, tri, f, 0, sh);
+                        if (GRAD) {
+                            // tangents only for the faces that survived culling, stored vertex by vertex
+                            VVert q;
+                            PVert pk;
+                            view_from_world<true>(C, w0, q);
+                            pk = project<true>(q);
+                            reinterpret_cast<float4*>(r)[5] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
+                            view_from_world<true>(C, w1, q);
+                            pk = project<true>(q);
+                            reinterpret_cast<float4*>(r)[6] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
+                            view_from_world<true>(C, w2, q);
+                            pk = project<true>(q);
+                            reinterpret_cast<float4*>(r)[7] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
+                        }
+                    };
+                    if (staged) {
+                        emit(reinterpret_cast<float*>(&s_rec[(wave * 64 + pre) * kRecPad]));
+                    } else {
+                        emit(rec + (size_t)pos * OCC_REC_STRIDE);
+                    }
+                    x0 = tri.tx0; y0 = tri.ty0; x1 = tri.tx1; y1 = tri.ty1;
+                } else {
+                    Tri tmp[2];
+                    int fl[2];
+                    clip_face_slow<GRAD>(pool_faces, pool_verts, c, S, vo, fo, f, ox, oy, oz, tmp, fl);
+                    write_record<GRAD>(rec + (size_t)pos * OCC_REC_STRIDE, bbs + pos, scan + pos, pos, tmp[0], f, fl[0], sh);
+                    x0 = tmp[0].tx0; y0 = tmp[0].ty0; x1 = tmp[0].tx1; y1 = tmp[0].ty1;
+                    if (cnt == 2) {
+                        write_record<GRAD>(rec + (size_t)(pos + 1) * OCC_REC_STRIDE, bbs + pos + 1, scan + pos + 1, pos + 1,
+                                           tmp[1], f, fl[1], sh);
+                        x0 = min(x0, tmp[1].tx0); y0 = min(y0, tmp[1].ty0);
+                        x1 = max(x1, tmp[1].tx1); y1 = max(y1, tmp[1].ty1);
+                    }
+                }
+                rx0 = min(rx0, x0); ry0 = min(ry0, y0);
+                rx1 = max(rx1, x1); ry1 = max(ry1, y1);
+            } else {
+                overflow = true;
+            }
+        }
+        if (staged) {  // wave-uniform
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            constexpr int kP = GRAD ? kRecParts : 5;  // parts this variant writes
+            float4* __restrict__ dst = reinterpret_cast<float4*>(rec + (size_t)wstart * OCC_REC_STRIDE);
+            const float4* src = &s_rec[wave * 64 * kRecPad];
+            for (int i = lane; i < nw * kP; i += 64) {
+                const int rj = i / kP, part = i - rj * kP;
+                dst[rj * kRecParts + part] = src[rj * kRecPad + part];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        total += itot;
+    }
+    if (overflow) atomicOr(&ws.status[env], OCC_STATUS_REC_OVERFLOW);
+    // object block rect: wave reduction, then one LDS atomic per wave
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        rx0 = min(rx0, __shfl_xor(rx0, m, 64));
+        ry0 = min(ry0, __shfl_xor(ry0, m, 64));
+        rx1 = max(rx1, __shfl_xor(rx1, m, 64));
+        ry1 = max(ry1, __shfl_xor(ry1, m, 64));
+    }
+    if (lane == 0) {
+        atomicMin(&s_rect[0], rx0);
+        atomicMin(&s_rect[1], ry0);
+        atomicMax(&s_rect[2], rx1);
+        atomicMax(&s_rect[3], ry1);
+    }
+    {
+        // SCAN ORDER of the raster kernel: (pixel bbox, key of the nearest vertex depth, record index) rows, written
+        // with the records in face order (mesh order is spatially coherent, which makes the chunk boxes selective);
+        // occ_sort_kernel re-orders dense objects front to back.  The depth keys make the raster kernel's
+        // pruning exact in ANY order; the order only decides how early it bites.
+        const int nr = min(total, rec_cap);
+        __syncthreads();  // scan[] of the whole object written (and s_rect complete)
+        chunk_boxes(scan, reinterpret_cast<uint4*>(ws.rec_cbox) + (size_t)eo * ((rec_cap + 63) >> 6), nr, wave, lane);
+    }
+    if (tid == 0) {
+        ws.nrec[eo] = min(total, rec_cap);
+        ws.objrect[eo * 4 + 0] = s_rect[0];
+        ws.objrect[eo * 4 + 1] = s_rect[1];
+        ws.objrect[eo * 4 + 2] = s_rect[2];
+        ws.objrect[eo * 4 + 3] = s_rect[3];
+    }
+}
