@@ -176,10 +176,34 @@ class SyntheticShapeNet:
                 "model_id": f"model_{idx:05d}"}
 
 
+class _GrowBuf:
+    """Append-only device array with geometric capacity growth: appending a mesh uploads that mesh only (the pool
+    of a ShapeNet-size dataset grows by a few models per step for a long time; re-packing everything on every
+    addition would make a step cost O(pool size))."""
+
+    def __init__(self, device, dtype, tail=(), min_cap=1 << 14):
+        self.device, self.dtype, self.tail, self.min_cap = device, dtype, tuple(tail), min_cap
+        self.t: Optional[torch.Tensor] = None
+        self.n = 0
+
+    def append(self, host: torch.Tensor) -> None:
+        k = int(host.shape[0])
+        need = self.n + k
+        cap = 0 if self.t is None else int(self.t.shape[0])
+        if need > cap:
+            grown = torch.empty((max(need, 2 * cap, self.min_cap),) + self.tail, dtype=self.dtype, device=self.device)
+            if self.n:
+                grown[: self.n].copy_(self.t[: self.n])  # device-to-device, stream-ordered
+            self.t = grown
+        if k:
+            self.t[self.n:need].copy_(host.to(self.dtype))
+        self.n = need
+
+
 class MeshPool:
     """Packed, GPU-resident pool: ``verts (sumV,3) f32``, ``faces (sumF,3) i32`` (vertex ids local to the mesh),
-    ``vert_off (M+1) i32``, ``face_off (M+1) i32``.  Meshes can be appended; the packed tensors are
-    re-uploaded lazily (``device_tensors``)."""
+    ``vert_off (M+1) i32``, ``face_off (M+1) i32`` (+ optional per-face texture atlases).  Meshes can be appended at any
+    time; ``device_tensors`` uploads the meshes added since the last call (only those) into growable device arrays."""
 
     def __init__(self, device):
         self.device = torch.device(device)
@@ -188,16 +212,24 @@ class MeshPool:
         self._atlas: List[Optional[torch.Tensor]] = []  # per mesh (F,R,R,3) f32 or None (white vertices)
         self.atlas_res = 0
         self._keys: Dict[object, int] = {}
-        self._packed = None
-        self._packed_atlas = (None, None)
         self.version = 0
+        self._max_faces = 0
+        self._flushed = 0  # meshes already on the device
+        self._sum_v = self._sum_f = self._sum_a = 0
+        self._d_verts = _GrowBuf(self.device, torch.float32, (3,))
+        self._d_faces = _GrowBuf(self.device, torch.int32, (3,))
+        self._d_voff = _GrowBuf(self.device, torch.int32, (), 1 << 10)
+        self._d_foff = _GrowBuf(self.device, torch.int32, (), 1 << 10)
+        self._d_atlas = _GrowBuf(self.device, torch.float32, (), 1 << 16)
+        self._d_aoff = _GrowBuf(self.device, torch.int64, (), 1 << 10)
+        self._any_atlas = False
 
     def __len__(self):
         return len(self._verts)
 
     @property
     def max_faces(self) -> int:
-        return max((int(f.shape[0]) for f in self._faces), default=0)
+        return self._max_faces
 
     def num_faces(self, mesh_id: int) -> int:
         return int(self._faces[mesh_id].shape[0])
@@ -221,10 +253,10 @@ class MeshPool:
         self._verts.append(verts)
         self._faces.append(faces)
         self._atlas.append(atlas)
+        self._max_faces = max(self._max_faces, int(faces.shape[0]))
         mid = len(self._verts) - 1
         if key is not None:
             self._keys[key] = mid
-        self._packed = None
         self.version += 1
         return mid
 
@@ -234,36 +266,49 @@ class MeshPool:
     def get_atlas(self, mesh_id: int) -> Optional[torch.Tensor]:
         return self._atlas[mesh_id]
 
+    def _flush(self) -> None:
+        """Upload the meshes added since the last flush."""
+        m0, m1 = self._flushed, len(self._verts)
+        if m0 == m1:
+            return
+        if m0 == 0:  # offsets arrays start with the leading zero
+            self._d_voff.append(torch.zeros(1, dtype=torch.int32))
+            self._d_foff.append(torch.zeros(1, dtype=torch.int32))
+        voff, foff, aoff = [], [], []
+        for m in range(m0, m1):
+            self._sum_v += int(self._verts[m].shape[0])
+            self._sum_f += int(self._faces[m].shape[0])
+            voff.append(self._sum_v)
+            foff.append(self._sum_f)
+            a = self._atlas[m]
+            if a is None:
+                aoff.append(-1)
+            else:
+                aoff.append(self._sum_a)
+                self._sum_a += a.numel()
+                self._any_atlas = True
+        self._d_verts.append(torch.cat(self._verts[m0:m1]))
+        self._d_faces.append(torch.cat(self._faces[m0:m1]))
+        self._d_voff.append(torch.tensor(voff, dtype=torch.int32))
+        self._d_foff.append(torch.tensor(foff, dtype=torch.int32))
+        self._d_aoff.append(torch.tensor(aoff, dtype=torch.int64))
+        chunks = [self._atlas[m].reshape(-1) for m in range(m0, m1) if self._atlas[m] is not None]
+        if chunks:
+            self._d_atlas.append(torch.cat(chunks))
+        self._flushed = m1
+
     def atlas_tensors(self):
         """(packed atlas floats, per-mesh float offsets int64 with -1 = untextured) on the device, or (None, None)."""
-        self.device_tensors()
-        return self._packed_atlas
+        self._flush()
+        if not self._any_atlas:
+            return None, None
+        return self._d_atlas.t[: self._sum_a], self._d_aoff.t[: self._flushed]
 
     def device_tensors(self):
-        if self._packed is None:
-            if not self._verts:
-                raise ValueError("empty mesh pool")
-            voff = np.zeros(len(self._verts) + 1, dtype=np.int32)
-            foff = np.zeros(len(self._verts) + 1, dtype=np.int32)
-            voff[1:] = np.cumsum([v.shape[0] for v in self._verts])
-            foff[1:] = np.cumsum([f.shape[0] for f in self._faces])
-            self._packed = (
-                torch.cat(self._verts).to(self.device),
-                torch.cat(self._faces).to(self.device),
-                torch.from_numpy(voff).to(self.device),
-                torch.from_numpy(foff).to(self.device),
-            )
-            if any(a is not None for a in self._atlas):
-                aoff, chunks, pos = [], [], 0
-                for a in self._atlas:
-                    if a is None:
-                        aoff.append(-1)
-                    else:
-                        aoff.append(pos)
-                        chunks.append(a.reshape(-1))
-                        pos += a.numel()
-                self._packed_atlas = (torch.cat(chunks).to(self.device),
-                                      torch.tensor(aoff, dtype=torch.int64).to(self.device))
-            else:
-                self._packed_atlas = (None, None)
-        return self._packed
+        """(verts, faces, vert_off, face_off) device arrays (views of the growable buffers)."""
+        if not self._verts:
+            raise ValueError("empty mesh pool")
+        self._flush()
+        m = self._flushed
+        return (self._d_verts.t[: self._sum_v], self._d_faces.t[: self._sum_f], self._d_voff.t[: m + 1],
+                self._d_foff.t[: m + 1])

@@ -210,3 +210,28 @@ def test_root_aliases_export_reference_names():
     assert [(k, v.default) for k, v in list(sig.parameters.items())[1:]] == [
         ("new_scene", True), ("radius", 4.0), ("azimuth", 0.0), ("elevation", 0.0)]
     assert list(inspect.signature(SubProcVecEnv.SimpleVecEnv.__init__).parameters) == ["self", "env_fns"]
+
+
+def test_mesh_pool_incremental_appends_keep_earlier_data():
+    """Meshes are appended for as long as the env runs: each flush uploads the new meshes only, earlier data and
+    offsets stay put, capacity growth copies what is already there."""
+    from occlusionenv_amd.meshes import MeshPool, icosphere
+
+    pool = MeshPool("cpu")
+    v, f = icosphere(2)
+    v = torch.as_tensor(v, dtype=torch.float32)
+    f = torch.as_tensor(f)
+    snapshots = []
+    for i in range(120):  # 120 x 162 verts crosses the initial capacity of 16384 rows
+        mid = pool.add(v + float(i), f, key=i, atlas=(torch.full((f.shape[0], 2, 2, 3), float(i)) if i % 3 == 0 else None))
+        assert mid == i
+        if i % 17 == 0 or i == 119:
+            pv, pf, vo, fo = pool.device_tensors()
+            assert len(vo) == i + 2 and int(vo[-1]) == (i + 1) * v.shape[0] and int(fo[-1]) == (i + 1) * f.shape[0]
+            snapshots.append(i)
+    pv, pf, vo, fo = pool.device_tensors()
+    for i in (0, 16, 17, 100, 119):
+        assert torch.equal(pv[vo[i]:vo[i + 1]], v + float(i)) and torch.equal(pf[fo[i]:fo[i + 1]].long(), f)
+    atlas, aoff = pool.atlas_tensors()
+    assert int(aoff[1]) == -1 and int(aoff[3]) == f.shape[0] * 12 and float(atlas[int(aoff[117])]) == 117.0
+    assert pool.max_faces == f.shape[0] and pool.version == 120
