@@ -151,6 +151,14 @@ class OcclusionEngine:
         n_slots = cus * self.waves_per_cu
         nat.check(self.lib.occ_workspace_query(C.byref(sc), n_slots, C.byref(sizes)), "occ_workspace_query")
         d = self.device
+        total = sum(getattr(sizes, f) for f, _ in sizes._fields_ if f.endswith("_bytes"))
+        free = torch.cuda.mem_get_info(d)[0] + sum(t.numel() * 4 for t in (self._ws_tensors or {}).values())
+        if total > free:
+            raise nat.NativeError(
+                f"render workspace needs {total / 2**30:.1f} GiB but only {free / 2**30:.1f} GiB are free: every "
+                f"(env, object) slot holds records for the LARGEST mesh of the pool ({self.pool.max_faces} faces); "
+                f"use fewer envs per GPU or keep very large meshes out of the pool (the reference skips > 250k faces)")
+        self._ws_tensors = None  # release the old workspace before allocating the new one
 
         def buf(nbytes):
             return torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=d)
