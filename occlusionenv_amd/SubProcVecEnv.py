@@ -140,7 +140,7 @@ class SimpleVecEnv(VecEnv):
         """Draw a new candidate scene for the given (EMPTY) reserve slots on the host and hand them to the device."""
         if not len(slots):
             return
-        from .environment import sample_scene
+        from .environment import MAX_MESH_FACES, sample_scene
 
         ds = self.envs[0].shapenet_dataset
         pool = self.engine.pool
@@ -150,7 +150,7 @@ class SimpleVecEnv(VecEnv):
                     ids, offs = sample_scene(ds, pool)
                 except (IndexError, KeyError, ValueError, OSError):
                     continue
-                if max(pool.num_faces(m) for m in ids) <= 250000:  # environment.py:296-298
+                if max(pool.num_faces(m) for m in ids) <= MAX_MESH_FACES:  # environment.py:296-298
                     break
             self._rs_scene[r] = (ids, offs)
             self._rs_state[r] = nat.RS_PENDING

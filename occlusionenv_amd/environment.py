@@ -18,6 +18,8 @@ Documented deviations (all from SURVEY.md §0):
 """
 from __future__ import annotations
 
+import os
+
 import random
 from typing import Dict, List, Optional, Tuple
 
@@ -33,6 +35,12 @@ from .spaces import Box
 # (environment.py:106,119); one process-wide unseeded generator has the same distribution and none of the
 # ~20 us construction cost per draw.
 _SCENE_RNG = np.random.default_rng()
+
+#: scenes containing a mesh with more faces than this are drawn again (the reference: 250 000,
+#: environment.py:296-298).  Every (env, object) slot of the render workspace holds records for the largest mesh in
+#: the pool, so lowering this bounds the memory of runs on datasets with a few huge models.
+MAX_MESH_FACES = int(os.environ.get("OCC_MAX_MESH_FACES", 250000))
+_OVERSIZE = set()  # (dataset id, model index) of models found to exceed it
 
 
 def seed_scene_rng(seed=None) -> None:
@@ -95,8 +103,15 @@ def sample_scene(dataset, pool: MeshPool, num_objects: int = 3) -> Tuple[List[in
             high_idx = low_idx + dataset.synset_num_models[category_id]
             model_idx = int(_SCENE_RNG.integers(low=low_idx, high=high_idx))
             key = (id(dataset), model_idx)
+            if key in _OVERSIZE:
+                raise ValueError("scene contains a mesh above MAX_MESH_FACES")  # callers draw again
             if key not in pool._keys:
                 obj = dataset[model_idx]
+                if int(obj["faces"].shape[0]) > MAX_MESH_FACES:
+                    # the reference loads it and then discards the scene (environment.py:296-298); here it never
+                    # enters the pool - the pool's largest mesh sizes every slot of the render workspace
+                    _OVERSIZE.add(key)
+                    raise ValueError("scene contains a mesh above MAX_MESH_FACES")
                 # environment.py:126-129: TexturesAtlas when the model has textures, else white TexturesVertex
                 pool.add(obj["verts"], obj["faces"], key=key, atlas=obj.get("textures"))
             ids.append(pool._keys[key])
@@ -207,7 +222,7 @@ class OcclusionEnv:
             ids, offs = sample_scene(self.shapenet_dataset, eng.pool)
         except (IndexError, KeyError, ValueError, OSError):
             return False
-        if max(eng.pool.num_faces(m) for m in ids) > 250000:  # environment.py:296-298
+        if max(eng.pool.num_faces(m) for m in ids) > MAX_MESH_FACES:  # environment.py:296-298
             return False
         self._scene = (ids, offs)
         if upload:

@@ -235,3 +235,28 @@ def test_mesh_pool_incremental_appends_keep_earlier_data():
     atlas, aoff = pool.atlas_tensors()
     assert int(aoff[1]) == -1 and int(aoff[3]) == f.shape[0] * 12 and float(atlas[int(aoff[117])]) == 117.0
     assert pool.max_faces == f.shape[0] and pool.version == 120
+
+
+def test_oversize_models_never_enter_the_pool(monkeypatch):
+    """environment.py:296-298 discards scenes with a mesh above 250 000 faces; here such a model is rejected before it
+    reaches the pool (the pool's largest mesh sizes the render workspace)."""
+    from occlusionenv_amd import environment
+    from occlusionenv_amd.meshes import MeshPool, SyntheticShapeNet
+
+    ds = SyntheticShapeNet(n_models=6, seed=3, mixed=True)
+    sizes = sorted({int(m[1].shape[0]) for m in ds.models})
+    assert len(sizes) >= 2
+    monkeypatch.setattr(environment, "MAX_MESH_FACES", sizes[0])
+    environment._OVERSIZE.clear()
+    environment.seed_scene_rng(0)
+    pool = MeshPool("cpu")
+    ok = rejected = 0
+    for _ in range(200):
+        try:
+            ids, offs = environment.sample_scene(ds, pool)
+            ok += 1
+            assert all(pool.num_faces(m) <= sizes[0] for m in ids)
+        except ValueError:
+            rejected += 1
+    assert ok > 0 and rejected > 0 and pool.max_faces <= sizes[0]
+    environment._OVERSIZE.clear()
