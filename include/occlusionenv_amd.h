@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define OCC_ABI_VERSION 2
+#define OCC_ABI_VERSION 3
 
 /* return codes */
 #define OCC_OK 0
@@ -111,6 +111,11 @@ typedef struct OccWorkspace {
     float* obj_hz;      /* (n_env,3,S,S) depth of the nearest face of the object (3e38 = none) */
     int32_t* obj_hrec;  /* (n_env,3,S,S) its record index, -1 = none */
     int32_t n_slots;    /* persistent waves = blocks the tile kernel is launched with */
+    /* Optional variable record layout: rec / rec_bbox / scan hold rec_total records in all and every (env, object)
+     * gets room for ITS mesh (2 x faces, rounded up to 64) at record offset rec_off[env*3+obj]; rec_off
+     * (3*n_env+1 int64) is filled by occ_render.  NULL = fixed stride rec_cap per (env, object). */
+    int64_t* rec_off;
+    int64_t rec_total;
 } OccWorkspace;
 
 typedef struct OccWorkspaceSizes {
@@ -118,6 +123,7 @@ typedef struct OccWorkspaceSizes {
         partials_bytes, status_bytes, offsets_bytes, obj_alpha_bytes, obj_grad_bytes, obj_hz_bytes,
         obj_hrec_bytes, rec_cbox_bytes, scan_bytes;
     int32_t n_slots; /* recommended persistent-wave count for this device */
+    size_t rec_off_bytes;
 } OccWorkspaceSizes;
 
 /* Outputs of one batched render (device pointers; any may be NULL if the flag is off). */
@@ -135,6 +141,10 @@ int occ_abi_version(void);
 int occ_device_cu_count(void);
 
 int occ_workspace_query(const OccScene* scene, int n_slots, OccWorkspaceSizes* out);
+
+/* Sizes of the record arrays (rec, rec_bbox, scan, rec_cbox, rec_off) of a variable-layout workspace holding
+ * rec_total records for n_env scenes; the other fields of *inout are left as occ_workspace_query set them. */
+int occ_record_sizes(int64_t rec_total, int n_env, OccWorkspaceSizes* inout);
 
 /*
  * Camera for N envs.  cam: (N,OCC_CAM_STRIDE) floats =

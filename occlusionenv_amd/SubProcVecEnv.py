@@ -209,6 +209,7 @@ class SimpleVecEnv(VecEnv):
             # save final observation where user can get it, then reset (SubProcVecEnv.py:211-214)
             infos.set(i, "terminal_observation", pend["term"][r:r + 1])
             self.envs[i]._scene = self._rs_scene[r]
+            eng.note_commit(i, r)
             self.envs[i].image = eng._res_fs[r:r + 1].clone()  # the slot's stored render (it will be overwritten)
         if rep[N + 2 * R + 1]:  # reserve exhausted: synchronous batched reset for the rest
             done_envs = set(np.nonzero(rep[:N])[0].tolist())

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OCC_HIP_LIB") or os.path.join(_HERE, "libocc_hip.so")
 
 # layout constants (must match include/occlusionenv_amd.h)
-ABI_VERSION = 2
+ABI_VERSION = 3
 CAM_STRIDE = 48
 REC_STRIDE = 32
 TILE = 8
@@ -64,6 +64,8 @@ class OccWorkspace(C.Structure):
         ("obj_hz", C.c_void_p),
         ("obj_hrec", C.c_void_p),
         ("n_slots", C.c_int32),
+        ("rec_off", C.c_void_p),
+        ("rec_total", C.c_int64),
     ]
 
 
@@ -85,6 +87,7 @@ class OccWorkspaceSizes(C.Structure):
         ("rec_cbox_bytes", C.c_size_t),
         ("scan_bytes", C.c_size_t),
         ("n_slots", C.c_int32),
+        ("rec_off_bytes", C.c_size_t),
     ]
 
 
@@ -114,6 +117,7 @@ SYMBOLS = {
     "occ_abi_version": (C.c_int, []),
     "occ_device_cu_count": (C.c_int, []),
     "occ_workspace_query": (C.c_int, [C.POINTER(OccScene), C.c_int, C.POINTER(OccWorkspaceSizes)]),
+    "occ_record_sizes": (C.c_int, [C.c_int64, C.c_int, C.POINTER(OccWorkspaceSizes)]),
     "occ_camera": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_int, C.c_void_p]),
     "occ_render": (C.c_int, [C.POINTER(OccScene), C.c_void_p, C.POINTER(OccWorkspace), C.POINTER(OccRenderOut),

@@ -92,13 +92,14 @@ __global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bp
         float cr = 1.f, cg = 1.f, cb = 1.f, depth = -1.f;
         if (hrec >= 0) {
             const int eo = env * 3 + hobj;
-            const float* __restrict__ r = P.ws.rec + ((size_t)eo * cap + hrec) * OCC_REC_STRIDE;
+            const RecSpan span = rec_span(P.ws, cap, eo);
+            const float* __restrict__ r = P.ws.rec + (span.base + hrec) * OCC_REC_STRIDE;
             const int fid = __float_as_int(r[R_ID]);
             const int mesh = P.sc.scene_mesh[eo];
             const int vo = P.sc.mesh_vert_off[mesh], fo = P.sc.mesh_face_off[mesh];
             const float ox = P.sc.scene_offset[eo * 3], oy = P.sc.scene_offset[eo * 3 + 1], oz = P.sc.scene_offset[eo * 3 + 2];
             // per-face shading terms from the setup kernel (flat_shade): one gather instead of face -> 3 vertices
-            const float amb_diff = __uint_as_float(reinterpret_cast<const uint4*>(P.ws.rec_bbox)[(size_t)eo * cap + hrec].w);
+            const float amb_diff = __uint_as_float(reinterpret_cast<const uint4*>(P.ws.rec_bbox)[span.base + hrec].w);
             const float spec = r[R_SPEC];
             const float* __restrict__ cm = P.cam + (size_t)env * OCC_CAM_STRIDE;
             // texel: white TexturesVertex interpolated with the (unclipped) barycentrics, or the face's atlas

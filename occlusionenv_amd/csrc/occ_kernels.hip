@@ -147,6 +147,18 @@ extern "C" int occ_workspace_query(const OccScene* scene, int n_slots, OccWorksp
     out->obj_hrec_bytes = N * 3 * S2 * sizeof(int32_t);
     out->status_bytes = N * sizeof(int32_t);
     out->n_slots = n_slots;
+    out->rec_off_bytes = (N * 3 + 1) * sizeof(int64_t);
+    return OCC_OK;
+}
+
+extern "C" int occ_record_sizes(int64_t rec_total, int n_env, OccWorkspaceSizes* io) {
+    if (!io || rec_total <= 0 || n_env <= 0 || (rec_total & 63)) return OCC_ERR_ARG;
+    const size_t T = (size_t)rec_total;
+    io->rec_bytes = T * OCC_REC_STRIDE * sizeof(float);
+    io->rec_bbox_bytes = T * 4 * sizeof(uint32_t);
+    io->scan_bytes = T * 4 * sizeof(uint32_t);
+    io->rec_cbox_bytes = (T / 64) * 4 * sizeof(uint32_t);
+    io->rec_off_bytes = ((size_t)n_env * 3 + 1) * sizeof(int64_t);
     return OCC_OK;
 }
 
@@ -198,6 +210,12 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(ws->queue, 0, 8 * 16 * sizeof(uint32_t), st) != hipSuccess) return OCC_ERR_LAUNCH;
     const int N = scene->n_env;
+    if (ws->rec_off) {
+        if (ws->rec_total <= 0 || (ws->rec_total & 63)) return OCC_ERR_ARG;
+        hipLaunchKernelGGL(occ_recoff_kernel, dim3(1), dim3(1024), 0, st, *scene, (long long*)ws->rec_off,
+                           (long long)ws->rec_total, ws->status);
+        OCC_DBG_SYNC("recoff");
+    }
     if (grad)
         hipLaunchKernelGGL(occ_setup_kernel<true>, dim3(N * 3), dim3(256), 0, st, *scene, cam, *ws);
     else

@@ -441,11 +441,12 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
         const float xf = -1.0f + (2.0f * (float)(S - 1 - xi) + 1.0f) / fS;
         const float yf = -1.0f + (2.0f * (float)(S - 1 - yi) + 1.0f) / fS;
         const int n = as_const(P.ws.nrec + eo)[0];
-        if (!OCC_BOUND(xi >= 0 && xi < S && yi >= 0 && yi < S && n >= 0 && n <= cap, 2, xi | (yi << 16), n)) continue;
+        if (!OCC_BOUND(xi >= 0 && xi < S && yi >= 0 && yi < S && n >= 0 && n <= rec_span(P.ws, cap, eo).cap, 2, xi | (yi << 16), n)) continue;
         OCC_STAT(0, 1);              // work items
-        const float* __restrict__ recs = P.ws.rec + (size_t)eo * cap * OCC_REC_STRIDE;
-        const uint4* __restrict__ bbs = reinterpret_cast<const uint4*>(P.ws.rec_bbox) + (size_t)eo * cap;
-        const uint4* __restrict__ scan = reinterpret_cast<const uint4*>(P.ws.scan) + (size_t)eo * cap;
+        const RecSpan span = rec_span(P.ws, cap, eo);
+        const float* __restrict__ recs = P.ws.rec + span.base * OCC_REC_STRIDE;
+        const uint4* __restrict__ bbs = reinterpret_cast<const uint4*>(P.ws.rec_bbox) + span.base;
+        const uint4* __restrict__ scan = reinterpret_cast<const uint4*>(P.ws.scan) + span.base;
 
         float hz = 3.0e38f;
         int hrec = 0x7FFFFFFF;
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
         // two-level scan: chunk boxes (one lane per 64-record chunk) -> candidate chunks -> their record boxes,
         // the next candidate chunk's row of boxes being fetched while the current one is processed
         const int nch = (n + 63) >> 6;
-        const uint4* __restrict__ cbx = reinterpret_cast<const uint4*>(P.ws.rec_cbox) + (size_t)eo * ((cap + 63) >> 6);
+        const uint4* __restrict__ cbx = reinterpret_cast<const uint4*>(P.ws.rec_cbox) + span.cbox;
         const uint4 kEmptyBox = make_uint4(0xFFFFu, 0u, 0xFFFFFFFFu, 0u);  // x0 = 65535 > any pixel: never overlaps
         int cwin = -64;
         unsigned long long cmask = 0;
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
                 cwin += 64;
                 if (cwin >= nch) return -1;
                 uint4 cb = kEmptyBox;
-                if (cwin + lane < nch && OCC_BOUND(nch <= ((cap + 63) >> 6), 7, nch, cap)) cb = cbx[cwin + lane];
+                if (cwin + lane < nch && OCC_BOUND(nch <= ((span.cap + 63) >> 6), 7, nch, span.cap)) cb = cbx[cwin + lane];
                 cmask = __ballot(touches(cb) && cb.z < thrB);
             }
             const int bit = __builtin_ctzll(cmask);
@@ -625,12 +626,12 @@ __global__ __launch_bounds__(64, OCC_RASTER_WAVES_PER_SIMD) void occ_raster_kern
         };
         int c = next_chunk();
         uint4 bb_cur = kEmptyBox;
-        if (c >= 0 && c * 64 + lane < n && OCC_BOUND(c * 64 + lane < cap, 8, c, n)) bb_cur = scan[c * 64 + lane];
+        if (c >= 0 && c * 64 + lane < n && OCC_BOUND(c * 64 + lane < span.cap, 8, c, n)) bb_cur = scan[c * 64 + lane];
         while (c >= 0) {
             OCC_WATCHDOG(33, c, n);
             const int cn = next_chunk();
             uint4 bb_nxt = kEmptyBox;
-            if (cn >= 0 && cn * 64 + lane < n && OCC_BOUND(cn * 64 + lane < cap, 9, cn, n)) bb_nxt = scan[cn * 64 + lane];
+            if (cn >= 0 && cn * 64 + lane < n && OCC_BOUND(cn * 64 + lane < span.cap, 9, cn, n)) bb_nxt = scan[cn * 64 + lane];
             const bool hit = touches(bb_cur) && bb_cur.z < thrB;
             const unsigned long long mask = __ballot(hit);
             OCC_STAT(5, 1);  // chunk rows scanned

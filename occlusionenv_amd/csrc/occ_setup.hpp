@@ -184,6 +184,78 @@ __device__ __forceinline__ void chunk_boxes(const uint4* __restrict__ scan, uint
     }
 }
 
+// Record span of (env, object) eo: fixed stride rec_cap, or the variable layout of OccWorkspace.rec_off
+struct RecSpan {
+    size_t base;  // first record
+    int cap;      // records reserved
+    size_t cbox;  // first chunk box
+};
+__device__ __forceinline__ RecSpan rec_span(const OccWorkspace& ws, int rec_cap, int eo) {
+    RecSpan r;
+    if (ws.rec_off) {
+        const long long b = ws.rec_off[eo];
+        r.base = (size_t)b;
+        r.cap = (int)(ws.rec_off[eo + 1] - b);
+        r.cbox = (size_t)(b >> 6);  // spans are multiples of 64 records
+    } else {
+        r.base = (size_t)eo * rec_cap;
+        r.cap = rec_cap;
+        r.cbox = (size_t)eo * ((rec_cap + 63) >> 6);
+    }
+    return r;
+}
+
+// Variable record layout: every (env, object) gets room for 2 x the faces of ITS mesh (a z-clipped face can split in
+// two), rounded up to 64; skipped scene rows get none.  One block: prefix sum over 3*n_env entries.
+// Objects that no longer fit into rec_total get an empty span and raise OCC_STATUS_REC_OVERFLOW.
+__global__ __launch_bounds__(1024) void occ_recoff_kernel(OccScene sc, long long* __restrict__ rec_off, long long rec_total,
+                                                          int* __restrict__ status) {
+    __shared__ long long s_part[16];
+    __shared__ long long s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = 3 * sc.n_env;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < M; base += 1024) {
+        const int i = base + tid;
+        long long c = 0;
+        if (i < M && !(sc.skip && sc.skip[i / 3])) {
+            const int mesh = sc.scene_mesh[i];
+            const int nF = sc.mesh_face_off[mesh + 1] - sc.mesh_face_off[mesh];
+            c = ((2ll * nF + 63) >> 6) << 6;
+        }
+        long long incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const long long t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) s_part[wave] = incl;
+        __syncthreads();
+        long long woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const long long v = s_part[w];
+            if (w < wave) woff += v;
+            tot += v;
+        }
+        const long long carry = s_carry;
+        if (i < M) {
+            const long long off = carry + woff + incl - c;
+            if (off + c > rec_total) {  // does not fit: empty span at the end of the buffer
+                rec_off[i] = rec_total;
+                if (c) atomicOr(&status[i / 3], OCC_STATUS_REC_OVERFLOW);
+            } else {
+                rec_off[i] = off;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    if (tid == 0) rec_off[M] = min(s_carry, rec_total);
+}
+
 // Objects with many visible faces (>= kSortMin records: a pixel then collects far more than K candidates) get
 // their scan order sorted front to back - bitonic sort of (depth key, record index) in LDS - so that the raster
 // kernel reaches "every pixel of the block holds its K nearest" after the nearest faces and skips the rest.
@@ -197,8 +269,9 @@ __global__ __launch_bounds__(256) void occ_sort_kernel(OccScene sc, OccWorkspace
     while (p2 < nr) p2 <<= 1;
     if (p2 > sort_cap) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint4* __restrict__ bbs = reinterpret_cast<const uint4*>(ws.rec_bbox) + (size_t)eo * sc.rec_cap;
-    uint4* __restrict__ scan = reinterpret_cast<uint4*>(ws.scan) + (size_t)eo * sc.rec_cap;
+    const RecSpan span = rec_span(ws, sc.rec_cap, eo);
+    const uint4* __restrict__ bbs = reinterpret_cast<const uint4*>(ws.rec_bbox) + span.base;
+    uint4* __restrict__ scan = reinterpret_cast<uint4*>(ws.scan) + span.base;
     for (int i = tid; i < p2; i += 256) s_keys[i] = i < nr ? (((unsigned long long)bbs[i].z << 32) | (unsigned)i) : ~0ull;
     __syncthreads();
     for (int k = 2; k <= p2; k <<= 1) {
@@ -223,7 +296,7 @@ __global__ __launch_bounds__(256) void occ_sort_kernel(OccScene sc, OccWorkspace
         scan[i] = make_uint4(bb.x, bb.y, bb.z, (uint32_t)j);
     }
     __syncthreads();
-    chunk_boxes(scan, reinterpret_cast<uint4*>(ws.rec_cbox) + (size_t)eo * ((sc.rec_cap + 63) >> 6), nr, wave, lane);
+    chunk_boxes(scan, reinterpret_cast<uint4*>(ws.rec_cbox) + span.cbox, nr, wave, lane);
 }
 
 struct CamRT {
@@ -358,7 +431,8 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
     load_camera<GRAD>(c, C);
     const int* __restrict__ pool_faces = sc.pool_faces;
     const float* __restrict__ pool_verts = sc.pool_verts;
-    const int S = sc.img, rec_cap = sc.rec_cap;
+    const RecSpan span = rec_span(ws, sc.rec_cap, eo);
+    const int S = sc.img, rec_cap = span.cap;
     if (tid == 0) {
         s_rect[0] = 1 << 20;
         s_rect[1] = 1 << 20;
@@ -366,9 +440,9 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
         s_rect[3] = -1;
     }
     __syncthreads();
-    float* __restrict__ rec = ws.rec + (size_t)eo * rec_cap * OCC_REC_STRIDE;
-    uint4* __restrict__ bbs = reinterpret_cast<uint4*>(ws.rec_bbox) + (size_t)eo * rec_cap;
-    uint4* __restrict__ scan = reinterpret_cast<uint4*>(ws.scan) + (size_t)eo * rec_cap;
+    float* __restrict__ rec = ws.rec + span.base * OCC_REC_STRIDE;
+    uint4* __restrict__ bbs = reinterpret_cast<uint4*>(ws.rec_bbox) + span.base;
+    uint4* __restrict__ scan = reinterpret_cast<uint4*>(ws.scan) + span.base;
     int total = 0;
     bool overflow = false;
     int rx0 = 1 << 20, ry0 = 1 << 20, rx1 = -1, ry1 = -1;  // this thread's share of the object's block rect
@@ -529,7 +603,7 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
         // pruning exact in ANY order; the order only decides how early it bites.
         const int nr = min(total, rec_cap);
         __syncthreads();  // scan[] of the whole object written (and s_rect complete)
-        chunk_boxes(scan, reinterpret_cast<uint4*>(ws.rec_cbox) + (size_t)eo * ((rec_cap + 63) >> 6), nr, wave, lane);
+        chunk_boxes(scan, reinterpret_cast<uint4*>(ws.rec_cbox) + span.cbox, nr, wave, lane);
     }
     if (tid == 0) {
         ws.nrec[eo] = min(total, rec_cap);

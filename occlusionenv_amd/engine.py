@@ -89,6 +89,11 @@ class OcclusionEngine:
         self._ws_key = None
         self._ws = None
         self._ws_tensors = None
+        self._rec_tensors = None   # rec / rec_bbox / scan / rec_cbox / rec_off: sized by the records actually needed
+        self._rec_total = 0
+        self._mesh_host = np.zeros((NT, 3), dtype=np.int64)  # host copy of _mesh_all (kept current before every launch)
+        self._faces_np = np.zeros(0, dtype=np.int64)
+        self._faces_ver = -1
         self._reserve_cam_done = False
         if self.R:
             # device-side auto-reset state (include/occlusionenv_amd.h: occ_auto_reset)
@@ -118,6 +123,7 @@ class OcclusionEngine:
             raise ValueError("mesh id outside the pool")
         self.scene_mesh[idx] = m.to(self.device)
         self.scene_offset[idx] = torch.as_tensor(offsets, dtype=torch.float32).reshape(-1, 3, 3).to(self.device)
+        self._mesh_host[np.asarray(env_ids, dtype=np.int64).reshape(-1)] = m.numpy()
 
     # ---- workspace ------------------------------------------------------------------------
     def _scene_struct(self, n, scene_mesh, scene_offset, skip=None) -> nat.OccScene:
@@ -139,41 +145,68 @@ class OcclusionEngine:
         # a z-clipped face can split in two: worst case 2 records per face
         return 2 * max(self.pool.max_faces, 1)
 
-    def _ensure_workspace(self) -> nat.OccWorkspace:
-        key = (self._rec_cap(), self.NT, self.S)
-        if self._ws_key == key:
-            return self._ws
-        sc = self._scene_struct(self.NT, self._mesh_all, self._off_all)
-        sizes = nat.OccWorkspaceSizes()
-        cus = self.lib.occ_device_cu_count()
-        if cus <= 0:
-            raise nat.NativeError("occ_device_cu_count failed")
-        n_slots = cus * self.waves_per_cu
-        nat.check(self.lib.occ_workspace_query(C.byref(sc), n_slots, C.byref(sizes)), "occ_workspace_query")
+    def _records_needed(self, mesh_ids) -> int:
+        """Records a launch over these scenes needs: 2 x faces of every object's mesh, rounded up to 64
+        (occ_recoff_kernel lays the spans out the same way)."""
+        if self._faces_ver != self.pool.version:
+            self._faces_np = np.array([self.pool.num_faces(m) for m in range(len(self.pool))], dtype=np.int64)
+            self._faces_ver = self.pool.version
+        f = self._faces_np[np.asarray(mesh_ids, dtype=np.int64).reshape(-1)]
+        return int((((2 * f + 63) >> 6) << 6).sum())
+
+    def note_commit(self, env_id: int, slot: int) -> None:
+        """The device installed reserve ``slot``'s scene in ``env_id`` (occ_auto_reset): keep the host copy current."""
+        self._mesh_host[env_id] = self._mesh_host[self.N + slot]
+
+    def _ensure_workspace(self, need_records: Optional[int] = None) -> nat.OccWorkspace:
+        """Fixed-size scratch (planes, K-buffers, ...) once; the record arrays hold ``rec_total`` records in a
+        variable layout (every object gets room for ITS mesh) and grow geometrically when a launch needs more."""
+        key = (self.NT, self.S)
         d = self.device
-        total = sum(getattr(sizes, f) for f, _ in sizes._fields_ if f.endswith("_bytes"))
-        free = torch.cuda.mem_get_info(d)[0] + sum(t.numel() * 4 for t in (self._ws_tensors or {}).values())
-        if total > free:
-            raise nat.NativeError(
-                f"render workspace needs {total / 2**30:.1f} GiB but only {free / 2**30:.1f} GiB are free: every "
-                f"(env, object) slot holds records for the LARGEST mesh of the pool ({self.pool.max_faces} faces); "
-                f"use fewer envs per GPU or keep very large meshes out of the pool (the reference skips > 250k faces)")
-        self._ws_tensors = None  # release the old workspace before allocating the new one
 
         def buf(nbytes):
             return torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=d)
 
-        t = dict(rec=buf(sizes.rec_bytes), rec_bbox=buf(sizes.rec_bbox_bytes), nrec=buf(sizes.nrec_bytes),
-                 objrect=buf(sizes.objrect_bytes), queue=buf(sizes.queue_bytes), lists=buf(sizes.lists_bytes),
-                 partials=buf(sizes.partials_bytes), status=buf(sizes.status_bytes), offsets=buf(sizes.offsets_bytes),
-                 obj_alpha=buf(sizes.obj_alpha_bytes), obj_grad=buf(sizes.obj_grad_bytes),
-                 obj_hz=buf(sizes.obj_hz_bytes), obj_hrec=buf(sizes.obj_hrec_bytes), rec_cbox=buf(sizes.rec_cbox_bytes), scan=buf(sizes.scan_bytes))
-        ws = nat.OccWorkspace()
-        for k, v in t.items():
-            setattr(ws, k, v.data_ptr())
-        ws.n_slots = sizes.n_slots
-        self._ws, self._ws_tensors, self._ws_key = ws, t, key
-        return ws
+        if self._ws_key != key:
+            sc = self._scene_struct(self.NT, self._mesh_all, self._off_all)
+            sizes = nat.OccWorkspaceSizes()
+            cus = self.lib.occ_device_cu_count()
+            if cus <= 0:
+                raise nat.NativeError("occ_device_cu_count failed")
+            n_slots = cus * self.waves_per_cu
+            nat.check(self.lib.occ_workspace_query(C.byref(sc), n_slots, C.byref(sizes)), "occ_workspace_query")
+            self._ws_tensors = None
+            t = dict(nrec=buf(sizes.nrec_bytes), objrect=buf(sizes.objrect_bytes), queue=buf(sizes.queue_bytes),
+                     lists=buf(sizes.lists_bytes), partials=buf(sizes.partials_bytes), status=buf(sizes.status_bytes),
+                     offsets=buf(sizes.offsets_bytes), obj_alpha=buf(sizes.obj_alpha_bytes),
+                     obj_grad=buf(sizes.obj_grad_bytes), obj_hz=buf(sizes.obj_hz_bytes), obj_hrec=buf(sizes.obj_hrec_bytes))
+            ws = nat.OccWorkspace()
+            for k, v in t.items():
+                setattr(ws, k, v.data_ptr())
+            ws.n_slots = sizes.n_slots
+            self._ws, self._ws_tensors, self._ws_key = ws, t, key
+            self._rec_tensors, self._rec_total = None, 0
+        if need_records is None:
+            need_records = self._records_needed(self._mesh_host)
+        if need_records > self._rec_total or self._rec_tensors is None:
+            total = max(need_records, int(self._rec_total * 1.5), 64)
+            total = ((total + 63) >> 6) << 6
+            sizes = nat.OccWorkspaceSizes()
+            nat.check(self.lib.occ_record_sizes(total, self.NT, C.byref(sizes)), "occ_record_sizes")
+            nbytes = sizes.rec_bytes + sizes.rec_bbox_bytes + sizes.scan_bytes + sizes.rec_cbox_bytes + sizes.rec_off_bytes
+            self._rec_tensors = None  # release the old arrays first
+            free = torch.cuda.mem_get_info(d)[0]
+            if nbytes > free:
+                raise nat.NativeError(
+                    f"the face records of this batch need {nbytes / 2**30:.1f} GiB ({total} records of 160 B) but only "
+                    f"{free / 2**30:.1f} GiB are free: use fewer envs per GPU or lower OCC_MAX_MESH_FACES")
+            r = dict(rec=buf(sizes.rec_bytes), rec_bbox=buf(sizes.rec_bbox_bytes), scan=buf(sizes.scan_bytes),
+                     rec_cbox=buf(sizes.rec_cbox_bytes), rec_off=buf(sizes.rec_off_bytes))
+            for k, v in r.items():
+                setattr(self._ws, k, v.data_ptr())
+            self._ws.rec_total = total
+            self._rec_tensors, self._rec_total = r, total
+        return self._ws
 
     @property
     def status(self) -> torch.Tensor:
@@ -197,7 +230,8 @@ class OcclusionEngine:
 
     def _render(self, idx: Optional[torch.Tensor], cam_mode: int, cam_input: Optional[torch.Tensor], flags: int):
         """Camera + render for all envs (idx None) or the compact subset idx.  Returns a dict of fresh tensors."""
-        ws = self._ensure_workspace()
+        rows = self._mesh_host[: self.N] if idx is None else self._mesh_host[idx.cpu().numpy()]
+        ws = self._ensure_workspace(self._records_needed(rows))
         d, S = self.device, self.S
         f32 = dict(dtype=torch.float32, device=d)
         if idx is None:
@@ -280,14 +314,15 @@ class OcclusionEngine:
             return t.expand(m).contiguous() if t.ndim == 0 else t.reshape(m).contiguous()
 
         rad, az, el = vec(radius), vec(azimuth), vec(elevation)
-        ws = self._ensure_workspace()
+        mesh_host = np.asarray(mesh_ids, dtype=np.int64).reshape(-1, 3)
+        ws = self._ensure_workspace(self._records_needed(mesh_host))
         S = self.S
         cam = torch.empty(m, nat.CAM_STRIDE, **f32)
         st = self._stream()
         nat.check(self.lib.occ_camera(nat.CAM_LOOKAT, None, _p(el), _p(az), _p(rad), _p(cam), None, m, st), "occ_camera")
         out = dict(obs=torch.empty(m, 4, S, S, **f32), full_state=torch.empty(m, S, S, 4, **f32),
                    loss=torch.empty(m, **f32), alphas=torch.empty(m, 3, S, S, **f32), cam=cam,
-                   radius=rad, azimuth=az, elevation=el, scene_mesh=smesh, scene_offset=soff)
+                   radius=rad, azimuth=az, elevation=el, scene_mesh=smesh, scene_offset=soff, mesh_host=mesh_host)
         ro = nat.OccRenderOut()
         ro.obs, ro.full_state, ro.loss, ro.alphas = (out["obs"].data_ptr(), out["full_state"].data_ptr(),
                                                      out["loss"].data_ptr(), out["alphas"].data_ptr())
@@ -303,6 +338,7 @@ class OcclusionEngine:
         c = torch.as_tensor(cand_ids, dtype=torch.long, device=self.device).reshape(-1)
         self.scene_mesh[e] = res["scene_mesh"][c]
         self.scene_offset[e] = res["scene_offset"][c]
+        self._mesh_host[np.asarray(env_ids, dtype=np.int64).reshape(-1)] = res["mesh_host"][np.asarray(cand_ids, dtype=np.int64).reshape(-1)]
         self.radius[e] = res["radius"][c]
         self.azimuth[e] = res["azimuth"][c]
         self.elevation[e] = res["elevation"][c]
@@ -319,24 +355,6 @@ class OcclusionEngine:
         pos = self.camera_position if idx is None else self.camera_position[idx]
         out = self._render(idx, nat.CAM_POSITION, pos, nat.RENDER_HARD)
         return out["obs"]
-
-    def set_reserve_scenes(self, slots, mesh_ids, offsets) -> None:
-        """Assign candidate scenes to reserve slots (rendered with radius 4, az = el = 0: reset()'s defaults,
-        which is what SimpleVecEnv's auto-reset uses, SubProcVecEnv.py:214).  The reserve block is mirrored on the
-        host and uploaded whole (two small contiguous copies, no scatter kernels)."""
-        if not len(slots):
-            return
-        m = np.asarray(mesh_ids, dtype=np.int32).reshape(-1, 3)
-        if int(m.min()) < 0 or int(m.max()) >= len(self.pool):
-            raise ValueError("mesh id outside the pool")
-        if self._rs_mesh_host is None:
-            self._rs_mesh_host = torch.zeros(self.R, 3, dtype=torch.int32).pin_memory()
-            self._rs_off_host = torch.zeros(self.R, 3, 3, dtype=torch.float32).pin_memory()
-        sl = np.asarray(slots, dtype=np.int64)
-        self._rs_mesh_host.numpy()[sl] = m
-        self._rs_off_host.numpy()[sl] = np.asarray(offsets, dtype=np.float32).reshape(-1, 3, 3)
-        self._mesh_all[self.N:].copy_(self._rs_mesh_host, non_blocking=True)
-        self._off_all[self.N:].copy_(self._rs_off_host, non_blocking=True)
 
     def set_reserve_state(self, state, tries) -> None:
         """Overwrite the device-side slot states (host-driven warm-up only; no step may be in flight)."""
@@ -374,6 +392,7 @@ class OcclusionEngine:
             self._rs_off_host = torch.zeros(self.R, 3, 3, dtype=torch.float32).pin_memory()
         self._rs_mesh_host.numpy()[sl] = m
         self._rs_off_host.numpy()[sl] = off.reshape(n, 3, 3)
+        self._mesh_host[self.N + sl] = m
         self._flip ^= 1
         host = self._refill_host[self._flip]
         h = host.numpy()
@@ -416,20 +435,6 @@ class OcclusionEngine:
         nat.check(self.lib.occ_step_flags(_p(done_u8), _p(loss_all), _p(self.status), self.N, self.R if loss_all is not None else 0,
                                           _p(flags), self._stream()), "occ_step_flags")
         return flags
-
-    def commit_from_reserve(self, env_ids, slots, out) -> None:
-        """Install reserve slots (rendered by the last step()) as the fresh reset() state of ``env_ids``: one
-        small H2D copy of the (dst, src) row pairs + one kernel (occ_reset_commit)."""
-        n = len(env_ids)
-        if not n:
-            return
-        pairs = torch.tensor([[e, self.N + r] for e, r in zip(env_ids, slots)], dtype=torch.int32).to(self.device, non_blocking=True)
-        nat.check(self.lib.occ_reset_commit(_p(pairs), n, _p(self._el_all), _p(self._az_all), _p(self._rad_all),
-                                            _p(self.camera_position), _p(self._cam_all), _p(self._alphas_all),
-                                            _p(self.full_reward), _p(self.object_mass), _p(self._mesh_all),
-                                            _p(self._off_all), _p(out["obs_all"]), _p(out["obs_all"]), _p(out["loss_all"]),
-                                            self.S, self._stream()), "occ_reset_commit")
-        out["_pairs"] = pairs
 
     def step(self, actions: torch.Tensor, env_ids=None, with_reserve: bool = False, pre_launch=None):
         """Batched step(): returns (obs (n,4,S,S), reward (n,) [autograd-attached], done (n,) bool, full_state, loss).

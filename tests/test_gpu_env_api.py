@@ -308,6 +308,34 @@ def test_dataset_generator_and_no_grad_steps(ds, tmp_path):
     assert set(infos[0].keys()) >= {"full_state", "position", "full_reward"}
 
 
+def test_record_arrays_follow_the_scenes_not_the_largest_mesh():
+    """Variable record layout: every (env, object) gets room for ITS mesh.  A pool that also holds a 20 480-face model
+    must not make every slot pay for it, and a scene that does use it still renders (the arrays grow on demand)."""
+    from tests.parity_utils import make_case
+    from occlusionenv_amd.engine import OcclusionEngine
+
+    N, S = 64, 64
+    case = make_case(N, 31, "mixed")
+    pool = case["pool"]
+    faces = [pool.num_faces(m) for m in range(len(pool))]
+    small = [m for m in range(len(pool)) if faces[m] == min(faces)]
+    big = faces.index(max(faces))
+    assert max(faces) >= 8 * min(faces)
+    eng = OcclusionEngine(pool, N, S)
+    ids = torch.tensor([[small[i % len(small)]] * 3 for i in range(N)])
+    eng.set_scene(list(range(N)), ids, case["offsets"])
+    eng.reset_render(None, 4.0, case["az"], 0.0)
+    eng.check_status()
+    need_small = N * 3 * 2 * min(faces)
+    assert need_small <= eng._rec_total < 2 * need_small, (eng._rec_total, need_small)
+    ids[5, 1] = big  # one object of one env is the big model
+    eng.set_scene([5], ids[5:6], case["offsets"][5:6])
+    obs, loss, fs = eng.reset_render(None, 4.0, case["az"], 0.0)
+    eng.check_status()
+    assert eng._rec_total >= need_small + 2 * max(faces) - 2 * min(faces) and eng._rec_total < N * 3 * 2 * max(faces) // 2
+    assert torch.isfinite(loss).all() and float(eng.alphas[5, 1].max()) > 0.5  # the big object is there
+
+
 def test_full_size_properties(ds):
     """BASELINE config 3 size (1024 envs, 128x128, ~5k-face meshes): properties that need no oracle."""
     from tests.parity_utils import make_case
