@@ -83,7 +83,8 @@ typedef struct OccScene {
     int32_t n_meshes;
     int32_t n_env;
     int32_t img;       /* S: image side in pixels, multiple of 8, <= 2048 */
-    int32_t rec_cap;   /* record capacity per (env, object); >= faces of the largest mesh (x2 if clipping may split) */
+    int32_t rec_cap;   /* fixed layout: record capacity of every (env, object), >= 2 x faces of the largest mesh;
+                          variable layout (OccWorkspace.rec_off): upper bound of any object's span */
     /* optional per-face texture atlases (PyTorch3D TexturesAtlas, environment.py:127,152,175); NULL = all white */
     const float* pool_atlas;        /* packed (sum over textured meshes of F*R*R*3) */
     const int64_t* mesh_atlas_off;  /* (n_meshes) float offset of each mesh's atlas in pool_atlas, -1 = white vertices */
