@@ -32,7 +32,7 @@ def b_alg_bytes(vf_sum: float, S: int) -> float:
     return 24.0 * vf_sum + 56.0 * S * S
 
 
-def build_env(workload: str, n_env: int, img: int, seed: int):
+def build_env(workload: str, n_env: int, img: int, seed: int, pool_models: int = 1024):
     from occlusionenv_amd.environment import OcclusionEnv, seed_scene_rng
     from occlusionenv_amd.meshes import SyntheticShapeNet
     from occlusionenv_amd.SubProcVecEnv import SimpleVecEnv
@@ -42,24 +42,23 @@ def build_env(workload: str, n_env: int, img: int, seed: int):
     if workload == "teapot":
         ds = None
     else:
-        ds = SyntheticShapeNet(n_models=64, seed=1234, mixed=(workload == "mixed"))
+        # pool of 1 024 procedural ShapeNet-size meshes, seed 1234 (94 MB on the device: beyond L2)
+        ds = SyntheticShapeNet(n_models=pool_models, seed=1234, mixed=(workload == "mixed"))
     venv = SimpleVecEnv([(lambda: OcclusionEnv(ds, img_size=img)) for _ in range(n_env)])
     venv.seed(seed)
     return venv, ds
 
 
-def cpu_baseline(venv, n_sample: int, img: int):
-    """Oracle (CPU restatement, 1 thread) timed on a bounded sample of the SAME scenes: reset-free step +
-    backward for n_sample envs."""
+def _oracle_envs(venv, idx, img):
+    """Oracle environments of the engine's current scenes ``idx`` (reset done, not timed) + one action each."""
     import torch as T
 
     from oracle import p3d_restate as O
 
-    T.set_num_threads(1)
     eng = venv.engine
-    t_tot, done_n = 0.0, 0
     az = eng.azimuth.cpu()
-    for i in range(n_sample):
+    out = []
+    for i in idx:
         ids, offs = venv.envs[i]._scene
         objs = []
         for m, o in zip(ids, offs):
@@ -67,15 +66,45 @@ def cpu_baseline(venv, n_sample: int, img: int):
             objs.append((v + T.tensor(o, dtype=T.float32), f))
         env = O.OracleEnv(objs, img)
         env.reset(azimuth=float(az[i]))  # not timed: state init only
-        a = T.randn(2, requires_grad=True)
-        t0 = time.perf_counter()
-        _, r, _, _ = env.step(a)
-        r.backward()
-        t_tot += time.perf_counter() - t0
+        out.append((env, T.randn(2, requires_grad=True)))
+    return out
+
+
+def _oracle_step(pair):
+    env, a = pair
+    t0 = time.perf_counter()
+    _, r, _, _ = env.step(a)
+    r.backward()
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(venv, n_sample: int, img: int, budget_s: float = 12.0):
+    """Oracle (CPU restatement of the reference's PyTorch3D CPU path) timed on a bounded sample of the SAME scenes:
+    reset-free step + backward.  Two legs: (i) 1 thread - the reference's own execution model
+    (naive rasteriser, serial SimpleVecEnv loop); (ii) env-parallel over all host cores, one env per thread (the C
+    rasteriser and torch ops release the GIL)."""
+    import concurrent.futures as cf
+
+    import torch as T
+
+    T.set_num_threads(1)
+    cores = os.cpu_count() or 1
+    envs = _oracle_envs(venv, range(min(n_sample, venv.num_envs)), img)
+    t_tot, done_n = 0.0, 0
+    for pair in envs:
+        t_tot += _oracle_step(pair)
         done_n += 1
-        if t_tot > 25.0:
+        if t_tot > budget_s:
             break
-    return done_n / t_tot, done_n
+    one = dict(value=done_n / t_tot, n=done_n)
+    # all-cores leg: `cores` fresh envs stepped concurrently, wall time of the whole batch
+    n_par = min(cores, venv.num_envs)
+    envs = _oracle_envs(venv, range(n_par), img)
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(_oracle_step, envs))
+    wall = time.perf_counter() - t0
+    return one, dict(value=n_par / wall, n=n_par, cores=cores)
 
 
 def main():
@@ -90,6 +119,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path on fewer GPUs than ranks (ranks share devices)")
     ap.add_argument("--cpu-sample", type=int, default=16)
+    ap.add_argument("--pool-models", type=int, default=1024, help="synthetic mesh pool size (SURVEY 8d: 1024, seed 1234)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -115,7 +145,7 @@ def main():
     from occlusionenv_amd import rollout
 
     lib = nat.load()
-    venv, ds = build_env(args.workload, args.envs, args.img, seed=42 + rank)
+    venv, ds = build_env(args.workload, args.envs, args.img, seed=42 + rank, pool_models=args.pool_models)
     eng = venv.engine
     # SURVEY.md §8d scene distribution: x2 ~ N(0,1) (np.random, seeded), az ~ U(-0.6, 0.6), el = 0; scenes pass
     # the reference's reset rejection loop (loss > 0.1, environment.py:327).  VecEnv.reset() itself draws
@@ -126,27 +156,21 @@ def main():
         venv._warm_reserve()
     dev = eng.device
     gen = torch.Generator(device=dev).manual_seed(7 + rank)
-    gathered = torch.empty(world * args.envs, rollout.RECORD_FLOATS, device=dev) if world > 1 else None
     # The per-step record exchange (pack 261 floats/env + one all-gather over RCCL) runs on its own HIP stream,
     # behind an event recorded after the step's launches: it overlaps the NEXT step's render (bandwidth-bound
-    # pooling + a latency-bound collective next to a VALU-bound raster kernel).
-    side = torch.cuda.Stream(device=dev) if world > 1 else None
+    # pooling + a latency-bound collective next to a VALU-bound raster kernel).  rollout.RecordExchange.
+    xch = rollout.RecordExchange(args.envs, dev, world) if world > 1 else None
     zeros_lp = torch.zeros(args.envs, device=dev)
 
     def one_step():
         actions = torch.randn(args.envs, 2, device=dev, generator=gen, requires_grad=True)
         obs, rewards, dones, infos = venv.step(actions)
         rewards.sum().backward()
-        if world > 1:
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(dev))
-            rew, act = rewards.detach(), actions.detach()
-            with torch.cuda.stream(side):
-                side.wait_event(ready)
-                rec = rollout.pack_records(obs, act, zeros_lp, rew, dones)
-                rollout.all_gather_records(rec, gathered)
-            for t in (obs, act, rew, dones):  # consumed on the side stream: keep their memory until it is done
-                t.record_stream(side)
+        if xch is not None:
+            xch.submit(obs, actions, zeros_lp, rewards, dones)
+            # the env's synchronous reset fallback writes reset observations into ``obs`` in place at the start of
+            # the next step: it must not overtake the side stream's read of it
+            venv.obs_consumer_event = xch.ready
         return actions.grad
 
     def barrier():
@@ -183,6 +207,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    raster_short = "occ_raster_kernel" if os.environ.get("OCC_RASTER", "")[:1] == "1" else "occ_raster2_kernel"
+    raster_name = raster_short + "<soft,hard,grad>"
     if rank == 0:
         total_envs = args.envs * world
         value = total_envs * args.steps / dt
@@ -197,15 +223,20 @@ def main():
         # of full-size steps only when no reset happened, else the plain mean
         avg_ms = ms_sum.value / max(launches.value, 1)
         achieved = b_launch / (avg_ms * 1e-3) / 1e9 if launches.value else None
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(prof):
+        # HBM traffic of the dominant kernel: NOT measured in this run (PMC counters need rocprofv3 passes of their
+        # own) - the committed summary of the latest round's passes over this same command line, labelled as such
+        traffic, traffic_src = None, None
+        for prof in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")), reverse=True):
             try:
-                pj = json.load(open(prof))
-                if pj.get("workload") == args.workload and pj.get("envs") == args.envs and pj.get("img") == args.img:
+                pj = json.load(open(os.path.join(ROOT, "profiles", prof)))
+                if pj.get("workload") == args.workload and pj.get("envs") == args.envs and pj.get("img") == args.img \
+                        and pj.get("pool_models", 64) == args.pool_models and pj.get("kernel_short", "occ_raster_kernel") == raster_short:
                     traffic = pj.get("hbm_bytes_per_launch")
+                    traffic_src = "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
+                                  "2*FETCH + WRITE; not collected in this run)" % prof
+                    break
             except Exception:  # noqa: BLE001
-                traffic = None
+                continue
         out = {
             # BASELINE.json's metric is quoted at 128x128 (the default --img); other sizes say so
             "metric": f"env steps/sec (batched renders) @{args.img}x{args.img}, 3 ShapeNet-size (~5k-face) meshes per env",
@@ -221,22 +252,27 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {args.envs} envs/GPU x {world} GPU, {args.img}x{args.img}, "
-                                   f"3 objects/env, K=100 soft x3 + hard RGB-D, forward + action gradient"
+                                   f"3 objects/env drawn from a pool of {args.pool_models if ds is not None else 1} meshes "
+                                   f"(seed 1234), K=100 soft x3 + hard RGB-D, forward + action gradient"
                                    + (", + RCCL all-gather of 1044-B rollout records" if world > 1 else ""),
-                       "envs_per_gpu": args.envs, "img": args.img, "faces_per_pixel": 100,
+                       "envs_per_gpu": args.envs, "img": args.img, "faces_per_pixel": 100, "pool_models": args.pool_models,
                        "sharding": f"env-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "occ_raster_kernel<soft,hard,grad>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": raster_name, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": b_launch, "avg_launch_ms": avg_ms,
                          "launches": launches.value,
                          "note": "VALU-bound rasterisation; compulsory bytes are ~1.47 MB/env-step (SURVEY 8d)"},
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
-            v, n_s = cpu_baseline(venv, args.cpu_sample, args.img)
-            out["cpu_baseline"] = {"value": v, "unit": "env-steps/s", "cores": 1, "kind": "port",
-                                   "sample": f"{n_s} env-steps (step + backward) of the same scenes, oracle/ C naive "
-                                             f"rasteriser + torch-CPU, 1 thread"}
+            one, par = cpu_baseline(venv, args.cpu_sample, args.img)
+            out["cpu_baseline"] = {"value": one["value"], "unit": "env-steps/s", "cores": 1, "kind": "port",
+                                   "sample": f"{one['n']} env-steps (step + backward) of the same scenes, oracle/ C naive "
+                                             f"rasteriser + torch-CPU, 1 thread (the reference's execution model)"}
+            out["cpu_baseline_all_cores"] = {"value": par["value"], "unit": "env-steps/s", "cores": par["cores"], "kind": "port",
+                                             "sample": f"{par['n']} env-steps, one env per thread on os.cpu_count() = "
+                                                       f"{par['cores']} threads"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define OCC_ABI_VERSION 3
+#define OCC_ABI_VERSION 4
 
 /* return codes */
 #define OCC_OK 0
@@ -92,6 +92,10 @@ typedef struct OccScene {
     /* optional (n_env) int32: nonzero = do not render this scene row in this launch (its outputs are left
      * untouched); used for reserve slots that are not under test (occ_auto_reset keeps it up to date) */
     const int32_t* skip;
+    /* optional (n_env,S,S) f32 weight of every pixel's term of the loss: loss = sum_p w_p * full_state[p,3]^2 and
+     * its gradient likewise (NULL = 1 everywhere = environment.py:381).  Images are not affected.  Used to score a
+     * region of interest, and by the parity tests to leave out pixels classified as exact ties. */
+    const float* pix_weight;
 } OccScene;
 
 /* Caller-allocated scratch; sizes from occ_workspace_query(). */

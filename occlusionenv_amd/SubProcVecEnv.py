@@ -30,54 +30,54 @@ from .engine import OcclusionEngine
 from .environment import shared_pool
 
 
-def copy_obs_dict(obs):
-    """Shallow copy of an OrderedDict of arrays (SubProcVecEnv.py:11-18)."""
-    assert isinstance(obs, OrderedDict), "unexpected type for observations '{}'".format(type(obs))
-    return OrderedDict([(k, v) for k, v in obs.items()])
-
-
-def _space_kind(space):
-    name = type(space).__name__
-    return "dict" if name == "Dict" else ("tuple" if name == "Tuple" else "plain")
-
-
-def dict_to_obs(space, obs_dict):
-    """Internal dict representation -> the type ``space`` implies (SubProcVecEnv.py:21-40)."""
-    kind = _space_kind(space)
-    if kind == "dict":
-        return obs_dict
-    if kind == "tuple":
-        assert len(obs_dict) == len(space.spaces), "size of observation does not match size of observation space"
-        return tuple((obs_dict[i] for i in range(len(space.spaces))))
-    assert set(obs_dict.keys()) == {None}, "multiple observation keys for unstructured observation space"
-    return obs_dict[None]
+def _structure(space):
+    """How a gym-style space is laid out, told by duck-typing (gym itself may be absent): a mapping of named
+    sub-spaces ("dict"), a sequence of them ("tuple"), or a single array space (None)."""
+    sub = getattr(space, "spaces", None)
+    if sub is None:
+        return None, {None: space}
+    if hasattr(sub, "items"):
+        return "dict", OrderedDict(sub.items())
+    return "tuple", OrderedDict(enumerate(sub))
 
 
 def obs_space_info(obs_space):
-    """(keys, shapes, dtypes) of a (possibly structured) observation space (SubProcVecEnv.py:43-70)."""
-    kind = _space_kind(obs_space)
+    """``(keys, shapes, dtypes)`` of an observation space, one entry per array it holds; a plain space has the single
+    key ``None`` (interface of /root/reference/SubProcVecEnv.py:43-70)."""
+    _, parts = _structure(obs_space)
+    keys = list(parts)
+    return keys, {k: parts[k].shape for k in keys}, {k: parts[k].dtype for k in keys}
+
+
+def dict_to_obs(space, obs_dict):
+    """Keyed buffers -> the container the space's structure implies: the dict itself, a tuple in sub-space order, or
+    the lone array (interface of /root/reference/SubProcVecEnv.py:21-40)."""
+    kind, parts = _structure(space)
+    if set(obs_dict) != set(parts):
+        raise AssertionError("observation keys %r do not match the observation space %r" % (sorted(map(str, obs_dict)), sorted(map(str, parts))))
     if kind == "dict":
-        assert isinstance(obs_space.spaces, OrderedDict), "Dict space must have ordered subspaces"
-        subspaces = obs_space.spaces
-    elif kind == "tuple":
-        subspaces = {i: space for i, space in enumerate(obs_space.spaces)}
-    else:
-        assert not hasattr(obs_space, "spaces"), "Unsupported structured space '{}'".format(type(obs_space))
-        subspaces = {None: obs_space}
-    keys, shapes, dtypes = [], {}, {}
-    for key, box in subspaces.items():
-        keys.append(key)
-        shapes[key] = box.shape
-        dtypes[key] = box.dtype
-    return keys, shapes, dtypes
+        return obs_dict
+    if kind == "tuple":
+        return tuple(obs_dict[k] for k in parts)
+    return obs_dict[None]
+
+
+def copy_obs_dict(obs):
+    """New OrderedDict over the same arrays (interface of /root/reference/SubProcVecEnv.py:11-18)."""
+    if not isinstance(obs, OrderedDict):
+        raise AssertionError("observations must be an OrderedDict, got %s" % type(obs).__name__)
+    return OrderedDict(obs.items())
 
 
 class _LazyInfos(Sequence):
     """``list[dict]`` look-alike whose dicts are built on first access (1024 dicts of tensor views per step
     would cost more host time than the render)."""
 
-    def __init__(self, engine, full_state, loss, resolve=None):
-        self._e, self._fs, self._loss = engine, full_state, loss
+    def __init__(self, position, full_state, loss, resolve=None):
+        # position: (N,3) camera positions AS OF THIS STEP (a snapshot: the auto-reset zeroes the rows of finished
+        # envs and the next step overwrites all of them; the reference's reset() rebinds camera_position instead,
+        # environment.py:302, so its info dict keeps the terminal step's tensor)
+        self._pos, self._fs, self._loss = position, full_state, loss
         self._extra = {}
         self._made = {}
         self._resolve = resolve  # called before the first read: lets the env finish its deferred bookkeeping
@@ -101,7 +101,7 @@ class _LazyInfos(Sequence):
             r, self._resolve = self._resolve, None
             r()
         if i not in self._made:
-            d = {"full_state": self._fs[i:i + 1], "position": self._e.camera_position[i],
+            d = {"full_state": self._fs[i:i + 1], "position": self._pos[i],
                  "full_reward": self._loss[i]}
             d.update(self._extra.get(i, {}))
             self._made[i] = d
@@ -132,6 +132,9 @@ class SimpleVecEnv(VecEnv):
         self._late = []                     # slots refilled AFTER the pairing of the step whose report is pending
         self._fin_recent = 0.0              # decaying maximum of the number of envs that finished in one step
         self._warm = False
+        # optional torch.cuda.Event: recorded by an asynchronous consumer of the last step's ``obs`` (another stream)
+        # once it has read it; the in-place reset fallback below waits on it before overwriting rows of ``obs``
+        self.obs_consumer_event = None
 
     def step_async(self, actions):
         self.actions = actions
@@ -217,6 +220,8 @@ class SimpleVecEnv(VecEnv):
             term = obs[left].clone()
             for j, i in enumerate(left):
                 infos.set(i, "terminal_observation", term[j:j + 1])
+            if self.obs_consumer_event is not None:
+                torch.cuda.current_stream(eng.device).wait_event(self.obs_consumer_event)
             obs[left] = self._reset_envs(left, torch.zeros(len(left)))[:, 0]
         # slots refilled after this report's pairing ran still read EMPTY in it: they are PENDING by now
         state[self._late] = nat.RS_PENDING
@@ -246,8 +251,9 @@ class SimpleVecEnv(VecEnv):
                 actions, with_reserve=True, pre_launch=lambda: empty.extend(self._drain(defer_refill=True)))
             # finished envs are reset ON THE DEVICE from the reserve (pairing + commit); the host reads the
             # report later (_drain).  NB out["obs_all"][:N] IS obs: the commit writes the reset observation in place
+            pos = eng.camera_position.clone()
             pend = eng.auto_reset(out)
-            infos = _LazyInfos(eng, full_state, loss, resolve=self._drain)
+            infos = _LazyInfos(pos, full_state, loss, resolve=self._drain)
             self._pending = (pend, obs, out, infos)
             # new candidate scenes for the slots emptied one step ago: off the critical path (the GPU is busy
             # with this step); they are rendered from the next step on
@@ -260,7 +266,7 @@ class SimpleVecEnv(VecEnv):
             return obs, rewards, dones, infos
         obs, rewards, dones, full_state, loss = eng.step(actions)
         flags = eng.step_flags(dones.to(torch.uint8), None)
-        infos = _LazyInfos(eng, full_state, loss)
+        infos = _LazyInfos(eng.camera_position.clone(), full_state, loss)
         fl = flags.cpu().numpy()
         if fl[-1]:
             eng.check_status()

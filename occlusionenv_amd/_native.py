@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OCC_HIP_LIB") or os.path.join(_HERE, "libocc_hip.so")
 
 # layout constants (must match include/occlusionenv_amd.h)
-ABI_VERSION = 3
+ABI_VERSION = 4
 CAM_STRIDE = 48
 REC_STRIDE = 32
 TILE = 8
@@ -43,6 +43,7 @@ class OccScene(C.Structure):
         ("mesh_atlas_off", C.c_void_p),
         ("atlas_res", C.c_int32),
         ("skip", C.c_void_p),
+        ("pix_weight", C.c_void_p),
     ]
 
 

@@ -49,11 +49,13 @@ __global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bp
     if (SOFT) {
         // environment.py:373: image = i1*i2 + i2*i3 + i1*i3 ; RGB of every silhouette is 1
         const float I = alpha[0] * alpha[1] + alpha[1] * alpha[2] + alpha[0] * alpha[2];
-        float lsum = live ? I * I : 0.f, ge = 0.f, ga = 0.f;
+        // optional per-pixel weight of the loss term (OccScene.pix_weight)
+        const float wpx = (live && P.sc.pix_weight) ? P.sc.pix_weight[(size_t)env * S * S + gp] : 1.0f;
+        float lsum = live ? wpx * (I * I) : 0.f, ge = 0.f, ga = 0.f;
         if (GRAD && live) {
             const float g0 = alpha[1] + alpha[2], g1 = alpha[0] + alpha[2], g2 = alpha[0] + alpha[1];
-            ge = 2.0f * I * (g0 * dae[0] + g1 * dae[1] + g2 * dae[2]);
-            ga = 2.0f * I * (g0 * daa[0] + g1 * daa[1] + g2 * daa[2]);
+            ge = wpx * (2.0f * I * (g0 * dae[0] + g1 * dae[1] + g2 * dae[2]));
+            ga = wpx * (2.0f * I * (g0 * daa[0] + g1 * daa[1] + g2 * daa[2]));
         }
         lsum = wave_sum(lsum);
         if (GRAD) {

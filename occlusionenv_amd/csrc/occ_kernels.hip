@@ -40,6 +40,7 @@ namespace occ {
 #include "occ_camera.hpp"
 #include "occ_setup.hpp"
 #include "occ_raster.hpp"
+#include "occ_raster2.hpp"
 #include "occ_combine.hpp"
 #include "occ_blend.hpp"
 #include "occ_reset.hpp"
@@ -137,7 +138,10 @@ extern "C" int occ_workspace_query(const OccScene* scene, int n_slots, OccWorksp
     out->nrec_bytes = N * 3 * sizeof(int32_t);
     out->objrect_bytes = N * 3 * 4 * sizeof(int32_t);
     out->queue_bytes = 8 * 16 * sizeof(uint32_t);  // eight queue heads, one 64-B line each
-    out->lists_bytes = (size_t)n_slots * OCC_LIST_CAP * 64 * 4 * sizeof(float);
+    {   // per-wave K-buffer: lane lists (occ_raster_kernel) or compacted log (occ_raster2_kernel)
+        const size_t a = (size_t)OCC_LIST_CAP * 64 * 4 * sizeof(float), b = OCC_LOG_BYTES;
+        out->lists_bytes = (size_t)n_slots * (a > b ? a : b);
+    }
     const size_t S2 = (size_t)scene->img * scene->img;
     out->partials_bytes = N * ((S2 + 255) / 256) * 4 * sizeof(float);
     out->offsets_bytes = (size_t)(8 * xcd_slots(scene->n_env) + 1) * sizeof(int32_t);
@@ -176,6 +180,17 @@ extern "C" int occ_camera(int mode, const float* action, float* el, float* az, c
 
 // OCC_DEBUG_SYNC=1 in the environment: every launch of occ_render is announced on stderr and waited for, so that a
 // faulting kernel is the last one named (diagnostics only; serialises the stream).
+// OCC_RASTER=1 selects the round-1 raster kernel (4x4 blocks x 4 face slots), anything else the pair-enumerating
+// 8x8-tile kernel (occ_raster2.hpp).  Both implement the same semantics; kept for A/B measurements.
+static int raster_variant() {
+    static int v = 0;
+    if (!v) {
+        const char* e = getenv("OCC_RASTER");
+        v = (e && e[0] == '1') ? 1 : 2;
+    }
+    return v;
+}
+
 static bool dbg_sync_on() {
     static int on = -1;
     if (on < 0) {
@@ -236,7 +251,8 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
     P.cam = cam;
     P.K = faces_per_pixel;
     P.ntx = scene->img / OCC_TILE;
-    hipLaunchKernelGGL(occ_scan_kernel, dim3(1), dim3(1024), 0, st, ws->objrect, ws->nrec, ws->offsets, N);
+    const int rv = raster_variant();
+    hipLaunchKernelGGL(occ_scan_kernel, dim3(1), dim3(1024), 0, st, ws->objrect, ws->nrec, ws->offsets, N, rv == 2 ? 1 : 0);
     OCC_DBG_SYNC("scan");
     if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
     const dim3 grid(ws->n_slots), block(64);
@@ -246,7 +262,10 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
     const dim3 cgrid(N * bpe), cblock(256);
 #define OCC_LAUNCH(SOFT_, HARD_, GRAD_)                                                             \
     do {                                                                                            \
-        hipLaunchKernelGGL((occ_raster_kernel<SOFT_, HARD_, GRAD_>), grid, block, 0, st, P);        \
+        if (rv == 2)                                                                                \
+            hipLaunchKernelGGL((occ_raster2_kernel<SOFT_, HARD_, GRAD_>), grid, block, 0, st, P);   \
+        else                                                                                        \
+            hipLaunchKernelGGL((occ_raster_kernel<SOFT_, HARD_, GRAD_>), grid, block, 0, st, P);    \
         OCC_DBG_SYNC("raster");                                                                     \
         if (prof) {                                                                                 \
             (void)hipEventRecord(g_prof_ev[2 * g_prof_n + 1], st);                                  \

@@ -327,8 +327,10 @@ __device__ __forceinline__ int perm_to_eo(int p, int mq, int n_env) {
 
 // One block: exclusive prefix sum of the block counts of every (env, object) rect, in XCD-major order
 // -> work-item offsets (8*MQ + 1 entries).
+// shift = 0: work item = one OCC_BLOCK x OCC_BLOCK block of the rect (occ_raster_kernel); shift = 1: one 2 x 2 group of
+// blocks = 8 x 8-pixel tile (occ_raster2_kernel).
 __global__ __launch_bounds__(1024) void occ_scan_kernel(const int* __restrict__ objrect, const int* __restrict__ nrec,
-                                                        int* __restrict__ offsets, int n_env) {
+                                                        int* __restrict__ offsets, int n_env, int shift) {
     __shared__ int s_part[16];
     __shared__ int s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -340,8 +342,8 @@ __global__ __launch_bounds__(1024) void occ_scan_kernel(const int* __restrict__ 
         int c = 0;
         const int eo = i < M ? perm_to_eo(i, mq, n_env) : -1;
         if (eo >= 0 && nrec[eo] > 0) {
-            const int w = objrect[4 * eo + 2] - objrect[4 * eo] + 1, h = objrect[4 * eo + 3] - objrect[4 * eo + 1] + 1;
-            c = (w > 0 && h > 0) ? w * h : 0;
+            const int x0 = objrect[4 * eo], y0 = objrect[4 * eo + 1], x1 = objrect[4 * eo + 2], y1 = objrect[4 * eo + 3];
+            if (x1 >= x0 && y1 >= y0 && x0 >= 0 && y0 >= 0) c = ((x1 >> shift) - (x0 >> shift) + 1) * ((y1 >> shift) - (y0 >> shift) + 1);
         }
         int incl = c;  // inclusive scan inside the wave
 #pragma unroll

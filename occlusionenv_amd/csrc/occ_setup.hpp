@@ -14,14 +14,23 @@ struct VVert {  // view-space vertex with tangents
     float de[3], da[3];
 };
 
-template <bool GRAD>
-__device__ __forceinline__ PVert project(const VVert& q) {
+// NB a surviving unclipped face is projected twice: before the block-wide compaction barrier, where finish_tri()
+// takes the ONE visibility decision and derives the conservative pixel bbox (both cross the barrier: the count in a
+// register, the bbox through LDS), and after it, for the record's DATA only (the world corners, not the projections,
+// are what a face keeps in registers).  The two inlined copies may round differently in the last bit (FMA
+// contraction); nothing is decided from the second one, and the bbox carries 1e-3 px of slack.
+__device__ __forceinline__ void project_pos(const VVert& q, PVert& p, float& iz) {
     // [P3D] x_ndc = x_view * s / z_view  
-    PVert p;
-    const float iz = 1.0f / q.v[2];
+    iz = 1.0f / q.v[2];
     p.x = q.v[0] * kProjScale * iz;
     p.y = q.v[1] * kProjScale * iz;
     p.z = q.v[2];
+}
+template <bool GRAD>
+__device__ __forceinline__ PVert project(const VVert& q) {
+    PVert p;
+    float iz;
+    project_pos(q, p, iz);
     if (GRAD) {
         p.t[0] = (kProjScale * q.de[0] - p.x * q.de[2]) * iz;
         p.t[1] = (kProjScale * q.de[1] - p.y * q.de[2]) * iz;
@@ -61,9 +70,9 @@ struct Tri {
 };
 
 // Returns false if the triangle can never be matched to a pixel (culled / degenerate / off screen).  EVERY field
-// is filled with in-range values either way: occ_setup_kernel evaluates a surviving face twice (once to count it,
-// once to write it) and the two inlined copies need not round alike (fp contraction), so the second evaluation
-// must be safe to use even where it would, by a hair, have decided differently.
+// is filled with in-range values either way (clamped pixel bbox), whatever the verdict.  occ_setup_kernel calls this
+// ONCE per unclipped face, before the compaction barrier; the verdict and the pixel bbox cross the barrier (count
+// in a register, bbox through LDS) and are not derived again.
 __device__ __forceinline__ bool finish_tri(Tri& t, int S) {
     const float x0 = t.v[0].x, y0 = t.v[0].y, x1 = t.v[1].x, y1 = t.v[1].y, x2 = t.v[2].x, y2 = t.v[2].y;
     // [P3D] face_area = EdgeFunction(v0; v1, v2); back faces are culled (environment.py:253,271)
@@ -321,12 +330,16 @@ __device__ __forceinline__ void world_corner(const float* __restrict__ pool_vert
     w[2] = pv[2] + oz;
 }
 
+__device__ __forceinline__ void view_pos(const CamRT& c, const float* w, VVert& q) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) q.v[j] = w[0] * c.R[j] + w[1] * c.R[3 + j] + w[2] * c.R[6 + j] + c.T[j];
+}
 template <bool GRAD>
 __device__ __forceinline__ void view_from_world(const CamRT& c, const float* w, VVert& q) {
+    view_pos(c, w, q);
+    if (GRAD) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        q.v[j] = w[0] * c.R[j] + w[1] * c.R[3 + j] + w[2] * c.R[6 + j] + c.T[j];
-        if (GRAD) {
+        for (int j = 0; j < 3; ++j) {
             q.de[j] = w[0] * c.dRe[j] + w[1] * c.dRe[3 + j] + w[2] * c.dRe[6 + j] + c.dTe[j];
             q.da[j] = w[0] * c.dRa[j] + w[1] * c.dRa[3 + j] + w[2] * c.dRa[6 + j] + c.dTa[j];
         }
@@ -406,6 +419,7 @@ template <bool GRAD>
 __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const float* __restrict__ cam, OccWorkspace ws) {
     __shared__ int s_wcnt[2][4];  // double-buffered: one barrier per 256-face round
     __shared__ int s_rect[4];
+    __shared__ uint2 s_box[256];  // pixel bbox of this thread's face as its ONE visibility evaluation found it
     __shared__ float4 s_rec[4 * 64 * kRecPad];  // per wave: the records of one round, staged for coalesced stores
     // (LDS stride 9 parts = 36 dwords: a 32-dword stride would put every lane's write on the same banks)
     const int eo = blockIdx.x;  // env*3 + object
@@ -479,6 +493,7 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
                 tri.v[1] = project<false>(q1);
                 tri.v[2] = project<false>(q2);
                 cnt = finish_tri(tri, S) ? 1 : 0;
+                s_box[tid] = make_uint2(tri.bbox.x, tri.bbox.y);  // read back by this thread only, after the barrier
             }
         }
         if (__ballot(slow)) {
@@ -513,6 +528,7 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
                 int x0, y0, x1, y1;
                 const Shade sh = flat_shade(w0, w1, w2, c[C_C], c[C_C + 1], c[C_C + 2]);
                 if (!slow) {
+                    // positions again (data only - the verdict and the pixel bbox are the ones found above)
                     Tri tri;
                     {
                         VVert q;
@@ -522,7 +538,13 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
                         tri.v[1] = project<false>(q);
                         view_from_world<false>(C, w2, q);
                         tri.v[2] = project<false>(q);
-                        finish_tri(tri, S);
+                        const uint2 bx = s_box[tid];
+                        const uint32_t zb = __float_as_uint(fmin3(tri.v[0].z, tri.v[1].z, tri.v[2].z));
+                        tri.bbox = make_uint4(bx.x, bx.y, (zb & 0x80000000u) ? ~zb : (zb | 0x80000000u), 0u);
+                        tri.tx0 = (int)(bx.x & 0xFFFFu) / OCC_BLOCK;
+                        tri.ty0 = (int)(bx.x >> 16) / OCC_BLOCK;
+                        tri.tx1 = (int)(bx.y & 0xFFFFu) / OCC_BLOCK;
+                        tri.ty1 = (int)(bx.y >> 16) / OCC_BLOCK;
                     }
                     auto emit = [&](float* __restrict__ r) {
                         write_record<false>(r, bbs + pos, scan + pos, pos, tri, f, 0, sh);
@@ -581,7 +603,7 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
         }
         total += itot;
     }
-    if (overflow) atomicOr(&ws.status[env], OCC_STATUS_REC_OVERFLOW);
+    if (overflow || total > rec_cap) atomicOr(&ws.status[env], OCC_STATUS_REC_OVERFLOW);
     // object block rect: wave reduction, then one LDS atomic per wave
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -606,10 +628,13 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
         chunk_boxes(scan, reinterpret_cast<uint4*>(ws.rec_cbox) + span.cbox, nr, wave, lane);
     }
     if (tid == 0) {
-        ws.nrec[eo] = min(total, rec_cap);
-        ws.objrect[eo * 4 + 0] = s_rect[0];
-        ws.objrect[eo * 4 + 1] = s_rect[1];
-        ws.objrect[eo * 4 + 2] = s_rect[2];
-        ws.objrect[eo * 4 + 3] = s_rect[3];
+        // more records than the span holds (OCC_STATUS_REC_OVERFLOW is set): the object is left out altogether
+        // rather than rendered from a truncated list whose last slot may never have been written
+        const bool fits = total <= rec_cap;
+        ws.nrec[eo] = fits ? total : 0;
+        ws.objrect[eo * 4 + 0] = fits ? s_rect[0] : (1 << 20);
+        ws.objrect[eo * 4 + 1] = fits ? s_rect[1] : (1 << 20);
+        ws.objrect[eo * 4 + 2] = fits ? s_rect[2] : -1;
+        ws.objrect[eo * 4 + 3] = fits ? s_rect[3] : -1;
     }
 }

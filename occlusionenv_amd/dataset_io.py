@@ -50,24 +50,44 @@ class RunWriter:
             pickle.dump(self.params, fh)
 
 
-def generate(venv, root: str, num_frames: int = 20, lr: float = 2.5e-2, first_run: int = 0, generator=None) -> int:
-    """datasetGenerator.py:76-124 for all envs of ``venv`` at once; returns the number of runs written."""
+def generate(venv, root: str, num_frames: int = 20, lr: float = 2.5e-2, first_run: int = 0, generator=None,
+             max_steps: int = 0) -> int:
+    """datasetGenerator.py:76-124 for all envs of ``venv`` at once; returns the number of runs written.
+
+    Like the reference, every run stays on ONE scene for all its frames: the envs are stepped through the engine
+    directly (``OcclusionEnv.step`` semantics, datasetGenerator.py:88), not through ``SimpleVecEnv.step`` whose
+    auto-reset would swap the scene of an env that reports ``finished`` -- the reference ignores ``finished`` here.
+    A frame whose gradient is NaN is retried with the SAME action from the pose the failed step left behind, without
+    advancing that run's frame counter (datasetGenerator.py:93-95 ``continue``s before drawing a new action)."""
     os.makedirs(root, exist_ok=True)
     N = venv.num_envs
     eng = venv.engine
     writers = [RunWriter(root, first_run + i) for i in range(N)]
     venv.reset()
-    for j in range(num_frames):
-        action = (lr * torch.randn(N, 2, device=eng.device, generator=generator)).requires_grad_(True)
-        obs, rewards, dones, infos = venv.step(action)
+    venv._drain()  # no auto-reset report may be pending while the engine is driven directly
+    frame = np.zeros(N, dtype=np.int64)
+    action = lr * torch.randn(N, 2, device=eng.device, generator=generator)
+    steps, max_steps = 0, max_steps or 50 * num_frames
+    while int(frame.min()) < num_frames:
+        if steps >= max_steps:
+            raise RuntimeError("generate(): gradients stayed NaN for %d steps" % steps)
+        steps += 1
+        a = action.clone().requires_grad_(True)
+        obs, rewards, dones, full_state, loss = eng.step(a)
         rewards.sum().backward()
-        grad = action.grad.detach().cpu().numpy()
+        grad = a.grad.detach().cpu().numpy()
         obs_h = obs.detach().cpu().numpy()
-        occl = torch.cat([infos[i]["full_state"] for i in range(N)])[..., 3].detach().cpu().numpy()
+        occl = full_state[..., 3].detach().cpu().numpy()
         el, az = eng.elevation.cpu().numpy(), eng.azimuth.cpu().numpy()
+        fresh = lr * torch.randn(N, 2, device=eng.device, generator=generator)
+        good = torch.zeros(N, dtype=torch.bool)
         for i in range(N):
-            if not np.isnan(grad[i]).any():  # datasetGenerator.py:94-95
-                writers[i].write_frame(j, obs_h[i], occl[i], float(el[i]), float(az[i]), grad[i])
+            if frame[i] < num_frames and not np.isnan(grad[i]).any():
+                writers[i].write_frame(int(frame[i]), obs_h[i], occl[i], float(el[i]), float(az[i]), grad[i])
+                frame[i] += 1
+                good[i] = True
+        good = good.to(eng.device)
+        action = torch.where(good[:, None], fresh, action)  # a new action only after a frame was written
     for w in writers:
         w.close()
     return N

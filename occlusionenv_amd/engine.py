@@ -59,7 +59,10 @@ class OcclusionEngine:
         self.N = int(n_env)
         self.S = int(img_size)
         self.K = int(faces_per_pixel)
-        self.waves_per_cu = int(waves_per_cu or os.environ.get("OCC_WAVES_PER_CU", 20))
+        # persistent waves per CU of the raster kernel: what its LDS / VGPR budget admits (occ_raster2_kernel: 14 KB of
+        # LDS per wave -> 11; the round-1 kernel, OCC_RASTER=1: 20)
+        default_wpc = 20 if os.environ.get("OCC_RASTER", "")[:1] == "1" else 11
+        self.waves_per_cu = int(waves_per_cu or os.environ.get("OCC_WAVES_PER_CU", default_wpc))
         d = self.device
         f32 = dict(dtype=torch.float32, device=d)
         N = self.N
@@ -95,6 +98,8 @@ class OcclusionEngine:
         self._faces_np = np.zeros(0, dtype=np.int64)
         self._faces_ver = -1
         self._reserve_cam_done = False
+        # optional (N,S,S) weight of every pixel's loss term (OccScene.pix_weight); None = 1 (environment.py:381)
+        self.pixel_weight: Optional[torch.Tensor] = None
         if self.R:
             # device-side auto-reset state (include/occlusionenv_amd.h: occ_auto_reset)
             i32 = dict(dtype=torch.int32, device=d)
@@ -126,7 +131,7 @@ class OcclusionEngine:
         self._mesh_host[np.asarray(env_ids, dtype=np.int64).reshape(-1)] = m.numpy()
 
     # ---- workspace ------------------------------------------------------------------------
-    def _scene_struct(self, n, scene_mesh, scene_offset, skip=None) -> nat.OccScene:
+    def _scene_struct(self, n, scene_mesh, scene_offset, skip=None, pix_weight=None) -> nat.OccScene:
         pv, pf, vo, fo = self.pool.device_tensors()
         sc = nat.OccScene()
         sc.pool_verts, sc.pool_faces = pv.data_ptr(), pf.data_ptr()
@@ -139,6 +144,10 @@ class OcclusionEngine:
             sc.pool_atlas, sc.mesh_atlas_off, sc.atlas_res = atlas.data_ptr(), aoff.data_ptr(), self.pool.atlas_res
         if skip is not None:
             sc.skip = skip.data_ptr()
+        if pix_weight is not None:
+            if pix_weight.shape != (n, self.S, self.S) or pix_weight.dtype != torch.float32 or not pix_weight.is_contiguous():
+                raise ValueError(f"pixel weights must be a contiguous float32 ({n}, {self.S}, {self.S}) tensor")
+            sc.pix_weight = pix_weight.data_ptr()
         return sc
 
     def _rec_cap(self) -> int:
@@ -264,7 +273,10 @@ class OcclusionEngine:
         if flags & nat.RENDER_GRAD:
             out["grad_elaz"] = torch.empty(n, 2, **f32)
             ro.grad_elaz = out["grad_elaz"].data_ptr()
-        sc = self._scene_struct(n, smesh, soff)
+        pw = None
+        if self.pixel_weight is not None:
+            pw = self.pixel_weight if idx is None else self.pixel_weight[idx].contiguous()
+        sc = self._scene_struct(n, smesh, soff, pix_weight=pw)
         nat.check(self.lib.occ_render(C.byref(sc), _p(cam), C.byref(ws), C.byref(ro), flags, self.K, st), "occ_render")
         if idx is not None:
             if cam_mode == nat.CAM_STEP:
@@ -274,7 +286,7 @@ class OcclusionEngine:
             if flags & nat.RENDER_SOFT:
                 self.alphas[idx] = alphas
         out["cam"] = cam
-        out["_keep"] = (smesh, soff, el, az, rad, cam_in)  # keep temporaries alive until the stream is done with them
+        out["_keep"] = (smesh, soff, el, az, rad, cam_in, pw)  # keep temporaries alive until the stream is done with them
         return out
 
     def reset_render(self, env_ids=None, radius=4.0, azimuth=0.0, elevation=0.0):
@@ -474,7 +486,6 @@ class OcclusionEngine:
 
     def _render_with_reserve(self, actions, flags, pre_launch=None):
         """One launch sequence over N stepping envs (OCC_CAM_STEP) + R reserve scenes (OCC_CAM_LOOKAT)."""
-        ws = self._ensure_workspace()
         d, S, N, NT = self.device, self.S, self.N, self.NT
         f32 = dict(dtype=torch.float32, device=d)
         st = self._stream()
@@ -488,15 +499,18 @@ class OcclusionEngine:
             g = torch.empty(NT, 2, **f32)
             ro.grad_elaz = g.data_ptr()
             out["grad_elaz"] = g[:N]
-        sc = self._scene_struct(NT, self._mesh_all, self._off_all, self._skip)
-        ver = self.pool.version
+        pw = None
+        if self.pixel_weight is not None:  # reserve rows (reset candidates) are scored unweighted
+            pw = torch.ones(NT, S, S, **f32)
+            pw[:N] = self.pixel_weight
         cam_args = (nat.CAM_STEP, _p(actions), _p(self._el_all), _p(self._az_all), _p(self._rad_all), _p(self._cam_all),
                     _p(self.camera_position), N, st)
         if pre_launch is not None:
             pre_launch()
-            if self.pool.version != ver:  # a fallback reset inside pre_launch added meshes: the pool was re-packed
-                ws = self._ensure_workspace()
-                sc = self._scene_struct(NT, self._mesh_all, self._off_all, self._skip)
+        # pre_launch may have installed other scenes (auto-reset commits; the synchronous fallback reset may pick
+        # larger models or grow the pool): size the record arrays and build the scene struct only now
+        ws = self._ensure_workspace()
+        sc = self._scene_struct(NT, self._mesh_all, self._off_all, self._skip, pix_weight=pw)
         nat.check(self.lib.occ_camera(*cam_args), "occ_camera")
         if not self._reserve_cam_done:  # reset() camera of the reserve rows: radius 4, az = el = 0, never changes
             nat.check(self.lib.occ_camera(nat.CAM_LOOKAT, None, _p(self._el_all[N:]), _p(self._az_all[N:]),
@@ -509,5 +523,5 @@ class OcclusionEngine:
         nat.check(self.lib.occ_render(C.byref(sc), _p(self._cam_all), C.byref(ws), C.byref(ro), flags, self.K, st),
                   "occ_render")
         out.update(obs=obs[:N], full_state=fs[:N], loss=loss[:N], cam=self._cam_all, obs_all=obs, loss_all=loss,
-                   full_state_all=fs)
+                   full_state_all=fs, _keep=pw)
         return out

@@ -21,12 +21,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def default_teapot_path() -> str:
-    """``./data/teapot.obj`` like the reference (environment.py:56), else the packaged data fixture."""
-    for p in ("./data/teapot.obj", os.path.join(_HERE, "..", "data", "teapot.obj"),
-              os.path.join(_HERE, "..", "tests", "golden", "teapot.obj")):
+    """``./data/teapot.obj`` like the reference (environment.py:56), else the copy shipped in this repo's data/."""
+    for p in ("./data/teapot.obj", os.path.join(_HERE, "..", "data", "teapot.obj")):
         if os.path.exists(p):
             return os.path.abspath(p)
-    raise FileNotFoundError("teapot.obj not found (looked in ./data and tests/golden)")
+    raise FileNotFoundError("teapot.obj not found (looked in ./data and <repo>/data)")
 
 
 def load_obj(path: str) -> Tuple[torch.Tensor, torch.Tensor]:

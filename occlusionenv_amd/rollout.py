@@ -60,3 +60,46 @@ def all_gather_records(rec: torch.Tensor, out: torch.Tensor = None) -> torch.Ten
         return out
     dist.all_gather_into_tensor(out, rec.contiguous())
     return out
+
+
+class RecordExchange:
+    """The per-step record exchange of the N-GPU rollout, off the step's critical path.
+
+    ``submit`` packs this rank's 261-float records and all-gathers them on a SECOND HIP stream, behind an event
+    recorded on the producing stream after the step's launches: the bandwidth-bound 8x8 pooling and the latency-bound
+    collective then overlap the next step's VALU-bound raster kernel instead of extending the step.  ``ready`` is an
+    event recorded on the side stream once the step's tensors have been consumed: whoever is about to overwrite
+    them in place (SimpleVecEnv's synchronous reset fallback writes into ``obs``) waits on it first.  On CPU tensors
+    (gloo rehearsal, tests) the same sequence runs inline."""
+
+    def __init__(self, n_local: int, device, world: int):
+        self.device = torch.device(device)
+        self.world = int(world)
+        self.cuda = self.device.type == "cuda"
+        self.side = torch.cuda.Stream(device=self.device) if (self.cuda and self.world > 1) else None
+        self.gathered = torch.empty(self.world * n_local, RECORD_FLOATS, device=self.device) if self.world > 1 else None
+        self.ready = None
+        self.last = None
+
+    def submit(self, obs, actions, logprob, rewards, dones) -> None:
+        rew, act = rewards.detach(), actions.detach()
+        if self.side is None:
+            rec = pack_records(obs, act, logprob, rew, dones)
+            self.last = all_gather_records(rec, self.gathered) if self.world > 1 else rec
+            return
+        produced = torch.cuda.Event()
+        produced.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(produced)
+            rec = pack_records(obs, act, logprob, rew, dones)
+            self.ready = torch.cuda.Event()
+            self.ready.record(self.side)  # obs / actions / rewards / dones have been read
+            self.last = all_gather_records(rec, self.gathered)
+        for t in (obs, act, logprob, rew, dones):  # consumed on the side stream: keep their memory until it is done
+            t.record_stream(self.side)
+
+    def wait(self) -> torch.Tensor:
+        """The gathered (world * n, 261) records of the last submit, visible to the current stream."""
+        if self.side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+        return self.last

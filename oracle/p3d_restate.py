@@ -254,6 +254,24 @@ def rasterize_meshes(face_verts, S, blur_radius, K, cull_backfaces=True, z_clip=
     return p2f, zbuf, bary, dists
 
 
+def pixel_candidates(face_verts, S, yi, xi, blur_radius, band=1e-3, cull_backfaces=True, max_out=4096, area_band=2e-9):
+    """Tie classifier support (tests/parity_utils.py): what the naive rasteriser computes at ONE pixel for every face
+    that is a candidate there or misses by a hair (raster_naive.c: orc_pixel_candidates).  face_verts (F,3,3) AFTER
+    clip_faces.  Returns dict of numpy arrays f, z, dist, minb, flags (1 inside, 2 candidate, 4 pz < 0, 8 = face area
+    within area_band of the kEpsilon visibility threshold)."""
+    fv = face_verts.detach().to(torch.float32).contiguous()
+    of = torch.empty(max_out, dtype=torch.int64)
+    oz, od, ob = (torch.empty(max_out, dtype=torch.float32) for _ in range(3))
+    ofl = torch.empty(max_out, dtype=torch.int32)
+    fn = lib().orc_pixel_candidates_f32
+    fn.restype = ctypes.c_int
+    n = fn(_ptr(fv), ctypes.c_int64(fv.shape[0]), S, S, int(yi), int(xi), ctypes.c_float(blur_radius), 1,
+           int(blur_radius > 0.0), int(cull_backfaces), ctypes.c_float(band), ctypes.c_float(area_band), _ptr(of), _ptr(oz),
+           _ptr(od), _ptr(ob), _ptr(ofl), max_out)
+    assert n >= 0
+    return dict(f=of[:n].numpy(), z=oz[:n].numpy(), dist=od[:n].numpy(), minb=ob[:n].numpy(), flags=ofl[:n].numpy())
+
+
 # ---- shaders (A.6, A.7) ---------------------------------------------------------------------
 def sigmoid_alpha_blend(dists, pix_to_face, sigma=SIGMA):
     """SoftSilhouetteShader (environment.py:263): (S,S,K) -> (S,S,4), RGB = 1."""
@@ -354,6 +372,13 @@ class OracleEnv:
             fs.append(f + off)
             off += v.shape[0]
         self.scene = (torch.cat(vs), torch.cat(fs))
+        # optional (S,S) weight of every pixel's term of the loss (tests: 0 on pixels classified as exact ties, so
+        # that loss / reward / gradient are compared over the remaining pixels; the product's OccScene.pix_weight)
+        self.pixel_weight = None
+
+    def _loss(self):
+        sq = self.image[..., 3] ** 2
+        return torch.sum(sq if self.pixel_weight is None else sq * self.pixel_weight.to(sq.dtype))
 
     def _render_all(self, R, T):
         S = self.S
@@ -371,8 +396,9 @@ class OracleEnv:
         self.elevation = torch.tensor([elevation], dtype=dt)
         self.azimuth = torch.tensor([azimuth], dtype=dt)
         R, T = look_at_view_transform(self.radius, self.elevation, self.azimuth)
+        self.R, self.T = R, T
         observation, self.image, self.alphas = self._render_all(R, T)
-        loss = torch.sum(self.image[..., 3] ** 2)
+        loss = self._loss()
         self.fullReward = loss.detach()
         self.objectMass = loss.detach() + 1
         return observation
@@ -391,7 +417,7 @@ class OracleEnv:
         T = translation_from(R, self.camera_position[None, :])
         self.R, self.T = R, T
         observation, self.image, self.alphas = self._render_all(R, T)
-        loss = torch.sum(self.image[..., 3] ** 2)
+        loss = self._loss()
         reward = self.fullReward - loss
         self.fullReward = loss.detach()
         finished = self.fullReward < 0.1

@@ -276,3 +276,61 @@ int FN(orc_rasterize_backward_dists)(const REAL* face_verts, const int64_t* pix_
     }
     return 0;
 }
+
+/*
+ * Diagnostic for the parity tests' tie classifier (tests/parity_utils.py): everything the naive rasteriser
+ * computes for ONE pixel, for every face that is a candidate there OR misses being one by a hair
+ * (dist within blur*(1+band), bbox widened by the same relative band, signed area within area_band of the
+ * kEpsilon visibility threshold).  No clipped-pair rule here (the classifier only asks how close a decision was).
+ * Rows: f, z (pz), dist (unsigned), minb = smallest of the perspective-corrected barycentrics (the `inside` test is
+ * minb > 0), flags: 1 = inside, 2 = candidate under the exact rule of orc_rasterize_naive, 4 = pz < 0,
+ * 8 = the face's area is within area_band of kEpsilon (visible / culled by a hair; such a face is reported
+ * whichever side it fell).  Returns the number of rows (<= max_out), -1 on bad args.
+ */
+int FN(orc_pixel_candidates)(const REAL* face_verts, int64_t F, int H, int W, int yi, int xi, REAL blur_radius,
+                             int perspective_correct, int clip_barycentric, int cull_backfaces, REAL band,
+                             REAL area_band, int64_t* out_f, REAL* out_z, REAL* out_dist, REAL* out_minb,
+                             int32_t* out_flags, int max_out) {
+    if (!face_verts || yi < 0 || yi >= H || xi < 0 || xi >= W || max_out <= 0) return -1;
+    const REAL sq_blur = (REAL)sqrt((double)blur_radius);
+    const REAL sq_wide = (REAL)sqrt((double)(blur_radius * ((REAL)1 + band))) + (REAL)1e-6;
+    const REAL yf = (REAL)-1 + ((REAL)2 * (REAL)(H - 1 - yi) + (REAL)1) / (REAL)H;
+    const REAL xf = (REAL)-1 + ((REAL)2 * (REAL)(W - 1 - xi) + (REAL)1) / (REAL)W;
+    const v2 pxy = {xf, yf};
+    int n = 0;
+    for (int64_t f = 0; f < F && n < max_out; ++f) {
+        const REAL* fv = face_verts + f * 9;
+        const v2 v0 = {fv[0], fv[1]}, v1 = {fv[3], fv[4]}, v2_ = {fv[6], fv[7]};
+        const REAL z0 = fv[2], z1 = fv[5], z2 = fv[8];
+        const REAL area = edge_fn(v0, v1, v2_);
+        const int hair = cull_backfaces ? (area > kEpsilon - area_band && area < kEpsilon + area_band)
+                                        : ((area > kEpsilon - area_band && area < kEpsilon + area_band) ||
+                                           (-area > kEpsilon - area_band && -area < kEpsilon + area_band));
+        const int visible = !(cull_backfaces && area < 0) && !(area <= kEpsilon && area >= -kEpsilon);
+        if (!visible && !hair) continue;
+        if (rmax(rmax(z0, z1), z2) < 0) continue;
+        const REAL bx0 = rmin(rmin(v0.x, v1.x), v2_.x), bx1 = rmax(rmax(v0.x, v1.x), v2_.x);
+        const REAL by0 = rmin(rmin(v0.y, v1.y), v2_.y), by1 = rmax(rmax(v0.y, v1.y), v2_.y);
+        if (!(bx0 - sq_wide <= xf && xf <= bx1 + sq_wide && by0 - sq_wide <= yf && yf <= by1 + sq_wide)) continue;
+        const int in_box = (bx0 - sq_blur <= xf && xf <= bx1 + sq_blur && by0 - sq_blur <= yf && yf <= by1 + sq_blur);
+        const v3 b0 = bary_coords(pxy, v0, v1, v2_);
+        const v3 b1 = perspective_correct ? bary_persp(b0, z0, z1, z2) : b0;
+        const v3 bc = clip_barycentric ? bary_clip(b1) : b1;
+        const REAL pz = bc.x * z0 + bc.y * z1 + bc.z * z2;
+        int amin;
+        const REAL dist = point_tri_dist(pxy, v0, v1, v2_, &amin);
+        const int inside = b1.x > 0 && b1.y > 0 && b1.z > 0;
+        const REAL minb = rmin(rmin(b1.x, b1.y), b1.z);
+        /* on (or a hair off) an edge: within 1e-6 NDC of the triangle's boundary */
+        const int near_inside = dist <= (REAL)1e-12;
+        if (!inside && !near_inside && !(dist < blur_radius * ((REAL)1 + band))) continue;
+        const int cand = visible && in_box && !(pz < 0) && (inside || dist < blur_radius);
+        out_f[n] = f;
+        out_z[n] = pz;
+        out_dist[n] = dist;
+        out_minb[n] = minb;
+        out_flags[n] = (inside ? 1 : 0) | (cand ? 2 : 0) | (pz < 0 ? 4 : 0) | (hair ? 8 : 0);
+        ++n;
+    }
+    return n;
+}

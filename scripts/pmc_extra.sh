@@ -16,15 +16,16 @@ done
 python - "$OUT" "$R" <<'PY'
 import collections, csv, glob, json, os, sys
 out, rnd = sys.argv[1], sys.argv[2]
+KEY = ("occ_raster_kernel" if os.environ.get("OCC_RASTER", "")[:1] == "1" else "occ_raster2_kernel") + "<true, true, true>"
 vals = {}
 for f in glob.glob(os.path.join(out, "p*", "*", "*counter_collection.csv")):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "occ_raster_kernel<true, true, true>" in r["Kernel_Name"]:
+        if KEY in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         vals[k] = sum(v) / len(v)
-json.dump({"kernel": "occ_raster_kernel<true, true, true>", "note": "per-launch means, default bench workload", "counters": vals},
+json.dump({"kernel": KEY, "note": "per-launch means, default bench workload", "counters": vals},
           open(os.path.join("profiles", f"{rnd}_pmc_extra.json"), "w"), indent=1)
 print(json.dumps(vals))
 PY

@@ -30,8 +30,9 @@ def counters(sub):
     return agg
 
 
-KEY = "occ_raster_kernel<true, true, true>"
-summary = {"kernel": KEY, "note": "per-launch means over the full-batch step launches; FETCH_SIZE/WRITE_SIZE in KiB as "
+SHORT = "occ_raster_kernel" if os.environ.get("OCC_RASTER", "")[:1] == "1" else "occ_raster2_kernel"
+KEY = SHORT + "<true, true, true>"
+summary = {"kernel": KEY, "kernel_short": SHORT, "note": "per-launch means over the full-batch step launches; FETCH_SIZE/WRITE_SIZE in KiB as "
            "rocprofv3 reports them; hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 x2 read "
            "correction of MI355X_MICROARCH.md (HBM section), calibrated there for wide coalesced streams only"}
 vals = {}
@@ -49,6 +50,7 @@ try:
     summary["workload"] = "shapenet5k"
     summary["envs"] = bj["config"]["envs_per_gpu"]
     summary["img"] = bj["config"]["img"]
+    summary["pool_models"] = bj["config"].get("pool_models", 64)
     summary["bench"] = {k: bj[k] for k in ("value", "ms_per_step", "roofline", "cpu_baseline") if k in bj}
     json.dump(bj, open(os.path.join(prof, f"{rnd}_bench.json"), "w"), indent=1)
 except Exception as e:  # noqa: BLE001

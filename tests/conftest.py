@@ -16,4 +16,4 @@ def pytest_configure(config):
 def teapot():
     from occlusionenv_amd.meshes import load_obj
 
-    return load_obj(os.path.join(ROOT, "tests", "golden", "teapot.obj"))
+    return load_obj(os.path.join(ROOT, "data", "teapot.obj"))

@@ -308,6 +308,42 @@ def test_dataset_generator_and_no_grad_steps(ds, tmp_path):
     assert set(infos[0].keys()) >= {"full_state", "position", "full_reward"}
 
 
+def test_dataset_generator_keeps_a_run_on_its_scene_when_envs_finish(tmp_path):
+    """datasetGenerator.py:80-117 never resets on ``finished``: all frames of a run come from one scene and one
+    camera trajectory.  Scenes whose objects do not overlap report finished = True at every step; the runs must
+    still walk on in 0.05-steps (an auto-reset would put elevation / azimuth back to 0)."""
+    import pickle
+
+    from occlusionenv_amd import dataset_io
+    from environment import OcclusionEnv
+    from SubProcVecEnv import SimpleVecEnv
+
+    N, F = 4, 5
+    venv = SimpleVecEnv([lambda: OcclusionEnv(None, img_size=64) for _ in range(N)])
+    eng = venv.engine
+    real_reset = venv.reset
+
+    def reset_far_apart():
+        obs = real_reset()
+        off = torch.zeros(N, 3, 3)
+        off[:, 1, 0], off[:, 1, 2] = 3.5, 1.0   # x2 = 3.5: the three teapots do not overlap on screen
+        off[:, 2, 0], off[:, 2, 2] = -3.5, 2.0
+        eng.set_scene(list(range(N)), eng.scene_mesh.cpu(), off)
+        eng.reset_render(None, 4.0, 0.0, 0.0)
+        return obs
+
+    venv.reset = reset_far_apart
+    assert dataset_io.generate(venv, str(tmp_path), num_frames=F) == N
+    for i in range(N):
+        arr = np.asarray(pickle.load(open(tmp_path / ("run_%d" % i) / "params.pickle", "rb"))).reshape(-1, 5)
+        assert arr.shape == (F, 5) and np.array_equal(arr[:, 0], np.arange(F))
+        traj = np.vstack([[0.0, 0.0], arr[:, 1:3]])
+        steps = np.linalg.norm(np.diff(traj, axis=0), axis=1)
+        assert np.allclose(steps, 0.05, atol=1e-5), steps  # one unit-normalised action per frame, no reset in between
+        assert np.isfinite(arr[:, 3:5]).all()
+    assert float(eng.full_reward.max()) < 0.1  # the scenes really were "finished" all along
+
+
 def test_record_arrays_follow_the_scenes_not_the_largest_mesh():
     """Variable record layout: every (env, object) gets room for ITS mesh.  A pool that also holds a 20 480-face model
     must not make every slot pay for it, and a scene that does use it still renders (the arrays grow on demand)."""
@@ -379,3 +415,59 @@ def test_full_size_properties(ds):
     reward2.sum().backward()
     p = perm.cuda()
     assert torch.equal(loss2, loss[p]) and torch.equal(obs2, obs[p]) and torch.equal(a2.grad, a.grad[p])
+
+
+def test_round1_faulting_launch_inputs_under_the_bounds_checked_build():
+    """Regression fixture for the GPU memory fault of round 1 (bench soak, step ~200-300; commit 1e5d0e4): the scene
+    rows and cameras of the launch that was about to run when the fault came (OCC_DEBUG_DUMP), replayed through
+    occ_render with the OCC_DBG_BOUNDS build, whose raster kernel checks every index it forms and records the first
+    violation.  Root cause then: a face counted as visible and re-judged invisible left a garbage block rect; the
+    setup kernel now takes ONE visibility decision per face (occ_setup.hpp).  Child process: the library is chosen
+    at load time."""
+    import os
+    import subprocess
+    import sys
+
+    from tests.parity_utils import ROOT
+
+    lib = os.path.join(ROOT, "occlusionenv_amd", "libocc_hip_bounds.so")
+    assert os.path.exists(lib), "run __graft_entry__.build() first"
+    code = r"""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+from occlusionenv_amd import _native as nat
+from occlusionenv_amd.engine import OcclusionEngine, _p
+from occlusionenv_amd.meshes import MeshPool, SyntheticShapeNet
+z = np.load(os.path.join(%r, "tests", "golden", "fault_scene_r01.npz"))
+NT = int(z["n_rows"])
+ds = SyntheticShapeNet(n_models=64, seed=1234)          # bench.py's round-1 pool
+pool = MeshPool("cuda")
+ids = [pool.add(*ds.models[i], key=("syn", i)) for i in range(64)]
+assert ids == list(range(64))
+eng = OcclusionEngine(pool, NT, 128)
+eng.set_scene(list(range(NT)), torch.from_numpy(z["mesh"]), torch.from_numpy(z["off"]))
+eng.cam.copy_(torch.from_numpy(z["cam"]).cuda())
+ws = eng._ensure_workspace()
+S = 128
+obs = torch.empty(NT, 4, S, S, device="cuda"); fs = torch.empty(NT, S, S, 4, device="cuda")
+loss = torch.empty(NT, device="cuda"); g = torch.empty(NT, 2, device="cuda")
+ro = nat.OccRenderOut()
+ro.obs, ro.full_state, ro.loss, ro.alphas, ro.grad_elaz = obs.data_ptr(), fs.data_ptr(), loss.data_ptr(), eng.alphas.data_ptr(), g.data_ptr()
+sc = eng._scene_struct(NT, eng.scene_mesh, eng.scene_offset)
+for _ in range(2):
+    nat.check(eng.lib.occ_render(C.byref(sc), _p(eng.cam), C.byref(ws), C.byref(ro),
+                                 nat.RENDER_SOFT | nat.RENDER_HARD | nat.RENDER_GRAD, 100, eng._stream()), "occ_render")
+torch.cuda.synchronize()
+eng.check_status()
+buf = (C.c_int * 8)()
+eng.lib.occ_debug_fault.argtypes = [C.POINTER(C.c_int)]
+assert eng.lib.occ_debug_fault(buf) == 0
+print("FAULT", list(buf), "finite", bool(torch.isfinite(loss).all() and torch.isfinite(g).all() and torch.isfinite(obs).all()),
+      "loss_sum", float(loss.sum()))
+""" % (ROOT, ROOT)
+    env = dict(os.environ, OCC_HIP_LIB=lib)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("FAULT")][-1]
+    assert "FAULT [0, 0, 0, 0, 0, 0, 0, 0] finite True" in line, line

@@ -1,5 +1,10 @@
 """GPU parity: HIP engine vs the CPU oracle on identical seeded scenes (tolerance 1e-4 fp32, BASELINE.json).
-Everything here goes through the C ABI (occlusionenv_amd/_native.py -> libocc_hip.so)."""
+Everything here goes through the C ABI (occlusionenv_amd/_native.py -> libocc_hip.so).
+
+Every pixel of obs / alphas / full_state must be within 1e-4 of the oracle, loss and reward within 1e-4, the action
+gradient within 1e-4 relative -- except pixels the oracle's own candidate dump shows to be EXACT TIES (a discrete
+decision taken by less than rounding; tests/parity_utils.py), which are few, individually verified, and weighted out
+of the loss on both sides."""
 import json
 import os
 import subprocess
@@ -8,19 +13,13 @@ import sys
 import pytest
 import torch
 
-from tests.parity_utils import ROOT, run_parity_case
+from tests.parity_utils import ROOT, TOL, check_result, run_parity_case
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-4  # BASELINE.json north_star: "within 1e-4 fp32"
 
 
-def _check(res, grad_tol=1e-3):
-    assert res["depth_mismatch"] < 2e-3, res  # pixels whose nearest face flips on a z near-tie
-    assert res["obs_maxabs"] < TOL and res["obs0_maxabs"] < TOL, res
-    assert res["alpha_maxabs"] < TOL and res["fs_maxabs"] < 3 * TOL, res
-    assert res["loss_rel"] < TOL and res["loss0_rel"] < TOL, res
-    assert res["reward_abs"] < TOL, res
-    assert res["grad_rel"] < grad_tol, res  # relative L2 of d reward / d action
+def _check(res):
+    check_result(res)
 
 
 def test_teapot_64():  # BASELINE config 1 scene, batched
@@ -50,21 +49,40 @@ def test_mixed_face_counts_128():  # 1280 / 5120 / 20480-face meshes in one batc
 
 def test_z_clipped_scene():
     # camera 1.2 from the origin: faces straddle z = 0.5 -> clip_faces cases 3 / 4 and the pair rule (A.3)
-    _check(run_parity_case(n_env=2, img=64, seed=7, mesh="teapot", az_range=0.3, radius=1.2), grad_tol=2e-3)
+    _check(run_parity_case(n_env=2, img=64, seed=7, mesh="teapot", az_range=0.3, radius=1.2))
 
 
 def test_texture_atlas_observation():
-    """ShapeNet-style per-face (F,4,4,3) atlases (TexturesAtlas, environment.py:127): RGB of the observation."""
-    res = run_parity_case(n_env=2, img=64, seed=9, mesh="textured")
-    # a texel index can flip where a barycentric coordinate sits on a cell boundary: allow a handful of pixels
-    assert res["depth_mismatch"] < 2e-3 and res["alpha_maxabs"] < TOL and res["loss_rel"] < TOL, res
-    assert res["obs_texel_mismatch"] < 2e-3, res
+    """ShapeNet-style per-face (F,4,4,3) atlases (TexturesAtlas, environment.py:127): RGB of the observation.  A
+    texel index can flip where a barycentric sits on a texel-cell boundary: such pixels are classified, not masked."""
+    _check(run_parity_case(n_env=2, img=64, seed=9, mesh="textured"))
 
 
 def test_texture_atlas_z_clipped():
     """Camera inside the scene: texels of z-clipped faces use barycentrics converted back to the original face."""
-    res = run_parity_case(n_env=2, img=64, seed=10, mesh="textured", radius=1.0)
-    assert res["depth_mismatch"] < 5e-3 and res["obs_texel_mismatch"] < 5e-3 and res["obs_maxabs"] < TOL, res
+    _check(run_parity_case(n_env=2, img=64, seed=10, mesh="textured", radius=1.0))
+
+
+@pytest.mark.parametrize("seed,mesh,img,az,radius", [
+    (130, "mixed", 64, 0.6, 4.0),      # round-1 sweep: alpha 1.1e-2 on one pixel (K-th / (K+1)-th depth near-tie)
+    (139, "textured", 96, 3.0, 4.0),   # round-1 sweep: loss 1.1e-4, alpha 1.5e-2
+    (1009, "synthetic", 96, 3.0, 4.0),  # round-1 sweep: action gradient 3.8e-3
+    (2025, "synthetic", 64, 3.0, 4.0),  # round-1 sweep: alpha 9e-4
+])
+def test_round1_sweep_misses_are_exact_ties(seed, mesh, img, az, radius):
+    """The seeds the round-1 randomised sweep flagged (gpurun_out/parity_sweep*.log, scripts/parity_sweep.py's case
+    table): every pixel beyond 1e-4 must be an exact tie according to the oracle's own candidate list, and with those
+    pixels weighted out loss / reward / gradient must meet 1e-4."""
+    _check(run_parity_case(n_env=2, img=img, seed=seed, mesh=mesh, az_range=az, radius=radius))
+
+
+def test_render_matches_oracle_render():
+    """OcclusionEnv.render() (environment.py:332-347): the hard-only kernel variant at the camera position the step
+    left behind, against OracleEnv.render()."""
+    res = run_parity_case(n_env=2, img=64, seed=31, mesh="synthetic", check_render=True)
+    _check(res)
+    res = run_parity_case(n_env=2, img=128, seed=32, mesh="teapot", check_render=True)
+    _check(res)
 
 
 def test_objects_out_of_view_and_on_the_border():
@@ -84,7 +102,7 @@ def test_far_camera_thousands_of_candidates_per_pixel():
     candidates -> the K-buffer lists fill up (OCC_LIST_CAP = 512 per lane) and are compacted inside the loop of the
     shipped library, pruning bounds tighten while faces are still arriving."""
     res = run_parity_case(n_env=2, img=64, seed=14, mesh="mixed", radius=30.0)
-    _check(res, grad_tol=5e-3)
+    _check(res)
 
 
 def test_img_512_reference_default_size():
@@ -137,3 +155,71 @@ def test_multi_step_trajectory_matches_oracle():
         assert abs(float(eng.elevation[0]) - float(env.elevation)) < 1e-6 and abs(float(eng.azimuth[0]) - float(env.azimuth)) < 1e-6
         assert torch.allclose(eng.camera_position[0].cpu(), env.camera_position.detach(), atol=1e-5)
         a_o = (a_o + lr * ao.grad).detach()
+
+
+def test_camera_degenerate_look_at_branch():
+    """[P3D] look_at_rotation's `C parallel to up` branch (x = normalize(cross(y, z)) when x ~ 0,
+    occ_camera.hpp) through OCC_CAM_POSITION, against the oracle; regular and near-degenerate positions alongside."""
+    import ctypes as C
+
+    from occlusionenv_amd import _native as nat
+    from oracle import p3d_restate as O
+
+    lib = nat.load()
+    pos = torch.tensor([[0.0, 4.0, 0.0], [0.0, -3.0, 0.0], [1e-3, 4.0, 1e-3], [2e-2, 4.0, 0.0], [0.0, 4.0, 3e-2],
+                        [1.0, 2.0, 3.0], [0.0, 0.0, 4.0], [-2.0, 0.5, -1.0]])
+    n = pos.shape[0]
+    d_pos = pos.cuda().contiguous()
+    cam = torch.zeros(n, nat.CAM_STRIDE, device="cuda")
+    out_pos = torch.zeros(n, 3, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nat.check(lib.occ_camera(nat.CAM_POSITION, C.c_void_p(d_pos.data_ptr()), None, None, None, C.c_void_p(cam.data_ptr()),
+                             C.c_void_p(out_pos.data_ptr()), n, st), "occ_camera")
+    cam = cam.cpu()
+    R = O.look_at_rotation(pos)
+    T = O.translation_from(R, pos)
+    # the degenerate rows really take the replacement branch in the oracle
+    x_axis = torch.nn.functional.normalize(torch.cross(torch.tensor([[0.0, 1.0, 0.0]]).expand(n, 3),
+                                                       torch.nn.functional.normalize(-pos, eps=1e-5), dim=1), eps=1e-5)
+    assert bool((x_axis[:3].abs() <= 5e-3).all()) and not bool((x_axis[5:].abs() <= 5e-3).all(dim=1).any())
+    assert torch.allclose(cam[:, nat.C_R:nat.C_R + 9].reshape(n, 3, 3), R, atol=2e-6), (cam[:, :9], R)
+    assert torch.allclose(cam[:, nat.C_T:nat.C_T + 3], T, atol=1e-5)
+    assert torch.equal(out_pos.cpu(), pos)
+
+
+def test_step_through_the_degenerate_camera_pose():
+    """A full step whose camera ends up (almost) on the +Y axis (az = el = pi/2 in step()'s convention,
+    environment.py:363-365): the look-at fallback feeds the whole render + gradient chain."""
+    import math
+
+    from tests.parity_utils import make_case, oracle_env
+    from occlusionenv_amd.engine import OcclusionEngine
+
+    img = 64
+    case = make_case(1, 41, "teapot")
+    eng = OcclusionEngine(case["pool"], 1, img)
+    eng.set_scene([0], case["mesh_ids"], case["offsets"])
+    eng.reset_render(None, 4.0, 0.0, 0.0)
+    env = oracle_env(case, 0, img)
+    env.reset(azimuth=0.0)
+    # put both sides just short of the pole, then step onto it: el, az -> pi/2
+    step = 0.05 / math.sqrt(2.0)
+    for e in (eng.elevation, eng.azimuth):
+        e.fill_(math.pi / 2 - step)
+    env.elevation.fill_(math.pi / 2 - step)
+    env.azimuth.fill_(math.pi / 2 - step)
+    a = torch.tensor([[1.0, 1.0]], device="cuda", requires_grad=True)
+    obs, r, d, fs, loss = eng.step(a)
+    r.sum().backward()
+    ao = torch.tensor([1.0, 1.0], requires_grad=True)
+    obs_o, r_o, d_o, info = env.step(ao)
+    r_o.backward()
+    assert torch.allclose(eng.camera_position[0].cpu(), env.camera_position.detach(), atol=1e-5)
+    assert abs(float(env.camera_position[0])) < 5e-3 and abs(float(env.camera_position[2])) < 5e-3  # on the axis
+    assert float((obs.cpu()[0] - obs_o[0].detach()).abs().max()) < TOL
+    assert abs(float(loss) - float(info["full_reward"])) / max(1.0, float(info["full_reward"])) < TOL
+    assert abs(float(r) - float(r_o)) < TOL
+    # the gradient is finite but not comparable here: on the pole x = cross(up, z) / 1e-5 has |x| ~ 4e-3 and its
+    # DIRECTION turns by O(1) per 4e-8 of camera motion, so d/d(el, az) amplifies last-bit differences by ~1e7
+    # (PyTorch3D's autograd does the same)
+    assert torch.isfinite(a.grad).all() and torch.isfinite(ao.grad).all()

@@ -154,12 +154,11 @@ def test_sample_scene_follows_reference_layout():
 def test_lazy_infos_behaves_like_list_of_dicts():
     from occlusionenv_amd.SubProcVecEnv import _LazyInfos
 
-    class E:
-        camera_position = torch.arange(12.0).reshape(4, 3)
-
+    pos = torch.arange(12.0).reshape(4, 3)
     fs, loss = torch.zeros(4, 2, 2, 4), torch.arange(4.0)
-    infos = _LazyInfos(E(), fs, loss)
+    infos = _LazyInfos(pos, fs, loss)
     assert len(infos) == 4 and set(infos[1]) == {"full_state", "position", "full_reward"}
+    assert infos[1]["position"].tolist() == [3.0, 4.0, 5.0]
     assert infos[2]["full_state"].shape == (1, 2, 2, 4) and float(infos[3]["full_reward"]) == 3.0
     infos.set(1, "terminal_observation", "x")
     assert infos[1]["terminal_observation"] == "x" and "terminal_observation" not in infos[0]
@@ -260,3 +259,70 @@ def test_oversize_models_never_enter_the_pool(monkeypatch):
             rejected += 1
     assert ok > 0 and rejected > 0 and pool.max_faces <= sizes[0]
     environment._OVERSIZE.clear()
+
+
+def test_h1_record_layout_matches_reference_fullnetwork_shapes():
+    """SURVEY §8a row H1 pin: the rollout record's feature block and the harness's batched / single-env conventions
+    match what the reference's own agent produces from an observation.  Shapes captured by importing
+    /root/reference/model.py (FullNetwork(8, dilation=2, separable=True), PPO.py:47,155-162) in the authoring
+    container: tests/golden/make_golden.py."""
+    import ast
+
+    import torch
+
+    from occlusionenv_amd import rollout
+
+    assert int(G["h1_param_count"]) == 1020902  # SURVEY.md §2 row 8
+    cases = ast.literal_eval(str(G["h1_shapes"]))
+    assert [c[0] for c in cases] == [[1, 4, 64, 64], [1, 4, 128, 128], [8, 4, 128, 128]]
+    for obs_shape, feats, segm, gradp, act, val in cases:
+        n, _, S, _ = obs_shape
+        obs = torch.rand(*obs_shape)
+        pooled = rollout.pooled_features(obs)
+        # the reference squeezes the batch axis of a single observation (model.py:162); the record keeps (n, 256)
+        assert list(pooled.shape) == [n, 256] and feats == ([256] if n == 1 else [n, 256])
+        assert segm == [n, 1, S, S] and gradp == ([2] if n == 1 else [n, 2])  # full-res segmentation, 2-d gradient head
+        assert act == ([2] if n == 1 else [n, 2]) and val == ([1] if n == 1 else [n, 1])
+        rec = rollout.pack_records(obs, torch.zeros(n, 2), torch.zeros(n), torch.zeros(n), torch.zeros(n, dtype=torch.bool))
+        # 256 features + action (action_scores' width) + logprob + reward + done (PPO.py:157-162, trainRL.py:203-204)
+        assert rec.shape == (n, rollout.RECORD_FLOATS) and rollout.RECORD_FLOATS == feats[-1] + act[-1] + 1 + 1 + 1
+
+
+def test_obs_space_helpers_cover_plain_dict_and_tuple_spaces():
+    """obs_space_info / dict_to_obs / copy_obs_dict (interface of /root/reference/SubProcVecEnv.py:11-70)."""
+    from collections import OrderedDict
+
+    from occlusionenv_amd.spaces import Box
+    from occlusionenv_amd.SubProcVecEnv import copy_obs_dict, dict_to_obs, obs_space_info
+
+    box = Box(0.0, 1.0, (4, 8, 8))
+    keys, shapes, dtypes = obs_space_info(box)
+    assert keys == [None] and shapes[None] == (4, 8, 8) and dtypes[None] == box.dtype
+    assert dict_to_obs(box, {None: "arr"}) == "arr"
+
+    class Dict:
+        def __init__(self, spaces):
+            self.spaces = OrderedDict(spaces)
+
+    class Tuple:
+        def __init__(self, spaces):
+            self.spaces = tuple(spaces)
+
+    small = Box(-1.0, 1.0, (2,))
+    d = Dict([("img", box), ("vec", small)])
+    keys, shapes, _ = obs_space_info(d)
+    assert keys == ["img", "vec"] and shapes == {"img": (4, 8, 8), "vec": (2,)}
+    buf = OrderedDict([("img", 1), ("vec", 2)])
+    assert dict_to_obs(d, buf) is buf
+    t = Tuple([box, small])
+    keys, shapes, _ = obs_space_info(t)
+    assert keys == [0, 1] and shapes[1] == (2,)
+    assert dict_to_obs(t, {0: "a", 1: "b"}) == ("a", "b")
+    with pytest.raises(AssertionError):
+        dict_to_obs(t, {0: "a"})
+    with pytest.raises(AssertionError):
+        dict_to_obs(box, {None: 1, "x": 2})
+    c = copy_obs_dict(buf)
+    assert c == buf and c is not buf
+    with pytest.raises(AssertionError):
+        copy_obs_dict({"img": 1})

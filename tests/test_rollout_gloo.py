@@ -62,3 +62,70 @@ def test_all_gather_records_world2_gloo():
     for rank, rewards, a0 in res:
         assert rewards == [float(i) for i in range(n_total)]  # rank-major == global env order
         assert a0 == [0.0] * 6 + [1.0] * 6
+
+
+class _StubVecEnv:
+    """Deterministic stand-in with SimpleVecEnv.step's return contract (no GPU): obs depends on (global env id, step)."""
+
+    def __init__(self, lo, hi, img=16):
+        self.lo, self.n, self.img, self.t = lo, hi - lo, img, 0
+        self.obs_consumer_event = None
+
+    def step(self, actions):
+        ids = torch.arange(self.lo, self.lo + self.n, dtype=torch.float32)
+        obs = (ids[:, None, None, None] + 0.01 * self.t) * torch.ones(self.n, 4, self.img, self.img)
+        rewards = (actions * actions).sum(1) + ids  # differentiable in the actions like the real reward
+        dones = (ids.long() + self.t) % 3 == 0
+        self.t += 1
+        return obs, rewards, dones, None
+
+
+def _bench_step_worker(rank, world, port, n_total, steps, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = rollout.env_shard(n_total, rank, world)
+    venv = _StubVecEnv(lo, hi)
+    xch = rollout.RecordExchange(hi - lo, "cpu", world)
+    gen = torch.Generator().manual_seed(7 + rank)
+    out = []
+    for _ in range(steps):  # bench.py: one_step()
+        actions = torch.randn(hi - lo, 2, generator=gen, requires_grad=True)
+        obs, rewards, dones, _ = venv.step(actions)
+        rewards.sum().backward()
+        xch.submit(obs, actions, torch.zeros(hi - lo), rewards, dones)
+        venv.obs_consumer_event = xch.ready
+        rec = xch.wait().clone()
+        out.append((rec[:, 0].tolist(), rec[:, 256:258].tolist(), rec[:, 259].tolist(), rec[:, 260].tolist(),
+                    actions.grad.tolist(), actions.detach().tolist()))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_step_sequence_world2_gloo():
+    """bench.py's one_step() (step -> backward -> RecordExchange.submit -> gathered records) on two gloo ranks with a
+    stub env: every rank ends up with ALL ranks' records in global env order, every step."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n_total, world, steps = 10, 2, 3
+    procs = [ctx.Process(target=_bench_step_worker, args=(r, world, port, n_total, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for t in range(steps):
+        f0, act, rew, dn, _, _ = res[0][t]
+        assert res[1][t][:4] == (f0, act, rew, dn)  # both ranks hold the same gathered table
+        assert [round(x - 0.01 * t, 4) for x in f0] == [float(i) for i in range(n_total)]  # pooled obs = global env id
+        assert dn == [1.0 if (i + t) % 3 == 0 else 0.0 for i in range(n_total)]
+        # the action columns are each rank's own actions, in shard order; gradients stayed local (2 * action)
+        mine = res[0][t][5] + res[1][t][5]
+        assert all(abs(a - b) < 1e-6 for ra, rb in zip(act, mine) for a, b in zip(ra, rb))
+        for r in range(world):
+            assert all(abs(g - 2 * a) < 1e-5 for rg, ra in zip(res[r][t][4], res[r][t][5]) for g, a in zip(rg, ra))
