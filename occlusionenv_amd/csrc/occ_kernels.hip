@@ -103,6 +103,14 @@ extern "C" int occ_debug_stats(unsigned long long* out8) {
 }
 #endif
 
+#ifdef OCC_DBG_TIME
+extern "C" int occ_debug_time(unsigned long long* out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(occ::g_dbg_time), 16 * sizeof(unsigned long long)) != hipSuccess) return 2;
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(occ::g_dbg_time), z, sizeof(z)) == hipSuccess ? 0 : 2;
+}
+#endif
+
 #ifdef OCC_DBG_BOUNDS
 extern "C" int occ_debug_fault(int* out8) {
     return hipMemcpyFromSymbol(out8, HIP_SYMBOL(occ::g_dbg_fault), 8 * sizeof(int)) == hipSuccess ? 0 : 2;

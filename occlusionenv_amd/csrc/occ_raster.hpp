@@ -30,8 +30,10 @@ struct Cand {
         ((PARTS) > 5 ? (src)[5] : make_float4(0, 0, 0, 0)), ((PARTS) > 5 ? (src)[6] : make_float4(0, 0, 0, 0)), \
         ((PARTS) > 5 ? (src)[7] : make_float4(0, 0, 0, 0))
 
-// Evaluate one projected face at this lane's pixel centre.
-template <bool SOFT, bool GRAD>
+// Evaluate one projected face at this lane's pixel centre.  EARLY: lanes outside the face's bbox leave at once (the
+// block kernel evaluates a face at all 16 pixels of a block, most of them outside); the pair kernel only visits
+// pixels of the face's pixel bbox, where a divergent early exit costs more than it saves: branch-free, masked at the end.
+template <bool SOFT, bool GRAD, bool EARLY = true>
 __device__ __forceinline__ void eval_face(OCC_REC_PARAMS, float xf, float yf, Cand& c) {
     c.cand = false;
     c.inside = false;
@@ -40,7 +42,7 @@ __device__ __forceinline__ void eval_face(OCC_REC_PARAMS, float xf, float yf, Ca
     c.ge = c.ga = 0.f;
     c.amin = 0;
     const bool inb = (rd.x <= xf) && (xf <= rd.y) && (rd.z <= yf) && (yf <= rd.w);
-    if (!inb) return;
+    if (EARLY && !inb) return;
     const float x0 = ra.x, y0 = ra.y, z0 = ra.z;
     const float x1 = ra.w, y1 = rb.x, z1 = rb.y;
     const float x2 = rb.z, y2 = rb.w, z2 = rc.x;
@@ -57,7 +59,7 @@ __device__ __forceinline__ void eval_face(OCC_REC_PARAMS, float xf, float yf, Ca
     const float p0 = w0 * rden, p1 = w1 * rden, p2 = w2 * rden;
     const bool inside = (p0 > 0.0f) && (p1 > 0.0f) && (p2 > 0.0f);
     c.zh = p0 * z0 + p1 * z1 + p2 * z2;
-    c.inside = inside && !(c.zh < 0.0f);
+    c.inside = inb && inside && !(c.zh < 0.0f);
     if (!SOFT) return;
     // clipped barycentrics -> soft depth
     float c0 = fmaxf(p0, 0.f), c1 = fmaxf(p1, 0.f), c2 = fmaxf(p2, 0.f);
@@ -86,7 +88,7 @@ __device__ __forceinline__ void eval_face(OCC_REC_PARAMS, float xf, float yf, Ca
     const bool s02 = !s01 && (d02 <= d01) && (d02 <= d12);
     const bool s12 = !s01 && !s02 && (d12 <= d01) && (d12 <= d02);
     c.amin = s01 ? 0 : (s02 ? 1 : 2);
-    const bool cand = !(pz < 0.0f) && (inside || dist < kBlurRadius);
+    const bool cand = inb && !(pz < 0.0f) && (inside || dist < kBlurRadius);
     c.cand = cand;
     c.z = pz;
     c.ad = dist;

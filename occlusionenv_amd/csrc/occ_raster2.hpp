@@ -11,40 +11,49 @@
 //     loop evaluates 64 consecutive pairs, each lane reading ITS face's record from an LDS image of the staged records
 //     (structure-of-parts, stride 65: conflict-free staging writes, near-broadcast reads - consecutive lanes
 //     share a face).
-//   * PER-PIXEL STATE IN LDS, updated with LDS atomics by whichever lane evaluated the candidate: count, largest key,
-//     sum of log2(1 - p_k) (the sigmoid-alpha PRODUCT in the log domain: prod = exp2(sum); one v_log_f32 per
-//     candidate, no cross-lane routing of products), the two tangent sums, nearest hard face as one 64-bit
-//     atomic min of (depth key << 32 | record).  A single wave owns the tile and LDS atomics of one instruction are
-//     applied in lane order, so results are reproducible and independent of the batch.
+//   * PER-PIXEL STATE IN LDS, updated by whichever lane evaluated the candidate with PLAIN read-modify-write (LDS
+//     atomics retire about one lane per cycle on gfx950: five of them per candidate cost more than the evaluation,
+//     measured 2.1 of 4.9 ms): (product of (1 - p_k), tangent sums, count) as one float4 and the largest key, in FOUR
+//     copies selected by (staged face & 3).  Lanes of one face hit distinct pixels, consecutive faces distinct
+//     copies, so a round is applied in sub-passes of four consecutive faces (usually two) and no two lanes of an
+//     instruction ever share an address; LDS operations of a wave retire in order.  The owner lane (lane = pixel)
+//     folds the four copies in a fixed order: results are reproducible and independent of the batch.  Nearest hard
+//     face: one 64-bit LDS atomic min of (depth key << 32 | record) per INSIDE pair (few).
 //   * K-BUFFER = WAVE-COMPACTED LOG.  Accepted candidates of a round are appended contiguously (ballot rank) to the
-//     wave's log in HBM/L2: key (4 B), owning pixel (1 B), payload (log2 q, g_el, g_az) - full-line coalesced stores
-//     instead of 64 partial lines.  The log is only read when some pixel of the tile collected more than K candidates.
+//     wave's log in HBM/L2: (key, owning pixel) 8 B + payload (1 - p, g_el, g_az) 16 B - full-line coalesced stores
+//     instead of 64 partial lines (measured: free next to the evaluation).  The log is only read when some pixel of
+//     the tile collected more than K candidates.
 //   * COOPERATIVE EXACT TOP-K.  Radix select (5 bits per level) over the log with all 64 lanes sweeping it
 //     contiguously; every entry bumps the LDS histogram of ITS pixel; the pixel's owner lane (lane = pixel) scans its
-//     32 buckets and narrows its window.  Afterwards one more sweep re-accumulates the kept entries of the
-//     overflowing pixels.  When the log fills up (thousands of candidates per pixel: far cameras, dense meshes) the
+//     32 buckets and narrows its window; sweeps keep eight 512-byte loads in flight (a sweep with one dependent
+//     load per iteration is pure L2 latency).  Afterwards one more sweep re-accumulates the kept entries of the
+//     overflowing pixels (log-domain product via LDS atomics: <= K entries per such pixel).  When the log fills up (thousands of candidates per pixel: far cameras, dense meshes) the
 //     same machinery keeps each overflowing pixel's K nearest and compacts the log in place; pruning bounds as before.
 //
 // Semantics are those of occ_raster.hpp: same eval_face, same candidate rule, same K-nearest-by-z
 // truncation, same clipped-pair rule, same hard nearest-face rule.
 
 #ifndef OCC_LOG_CAP
-#define OCC_LOG_CAP 12288  // log entries per wave; must exceed 64 * OCC_MAX_K + 64 (a compacted log plus one round)
+#define OCC_LOG_CAP 12288  // log entries per wave; must hold a compacted log (64 * OCC_MAX_K) plus the pairs of one batch
 #endif
-static_assert(OCC_LOG_CAP >= 64 * OCC_MAX_K + 128, "OCC_LOG_CAP too small");
-#define OCC_LOG_BYTES ((size_t)OCC_LOG_CAP * 24)  // 16 B payload + 4 B key + 1 B pixel tag (padded to 4)
+static_assert(OCC_LOG_CAP >= 64 * OCC_MAX_K + 2048 + 64, "OCC_LOG_CAP too small");
+#define OCC_LOG_BYTES ((size_t)OCC_LOG_CAP * 24)  // 16 B payload + 8 B (key, pixel)
 
 constexpr int kT2 = 8;         // tile side in pixels (== OCC_TILE)
-constexpr int kStg2 = 64;      // faces staged per batch: one per lane for the pair-count prefix sum
-constexpr int kStgPad = 65;    // LDS stride (float4) between the parts of the staged records
-constexpr int kPairCap = 1024; // pair descriptors per expansion window
-constexpr int kSelBits = 5;    // radix-select digit: 32 u16 buckets = 16 dwords per pixel
+constexpr int kStg2 = 32;      // faces staged per batch (LDS budget: 12 waves per CU need <= 13.3 KB each)
+constexpr int kStgPad = 33;    // LDS stride (float4) between the parts of the staged records (odd: conflict-free staging)
+constexpr int kPairCap = 2048; // pairs per batch at most (kStg2 faces x 64 pixels): one byte each in the pair map
+constexpr int kSelBits = 5;    // radix-select digit: 32 u16 buckets = 16 dwords per pixel (4 KB, aliasing records + descriptors)
 constexpr int kSelDw = (1 << kSelBits) / 2;
+constexpr int kSweepU = 8;     // 64-entry rows of the log per group of the final sweep
+constexpr int kHistU = 8;      // 128-entry double rows in flight in a histogram sweep
+constexpr int kListCap = 8;    // boundary-bucket entries per pixel that the owner lane resolves itself
+constexpr int kCopies = 4;     // accumulator copies (staged face & 3)
+constexpr int kAccStride = 73; // float4 slots per copy: pixel slot = 9 * py + px, copy stride = 9 mod 16 -> bank-spread
 
 struct WaveLog {
-    float4* __restrict__ pay;    // (log2(1-p), g_el, g_az, -)
-    uint32_t* __restrict__ key;  // order-preserving depth key
-    uint8_t* __restrict__ tag;   // pixel of the tile (0..63)
+    float4* __restrict__ pay;  // (1 - p, g_el, g_az, -)
+    uint2* __restrict__ kt;    // (order-preserving depth key, pixel of the tile 0..63)
 };
 
 __device__ __forceinline__ float unzkey(uint32_t k) {
@@ -54,6 +63,17 @@ __device__ __forceinline__ float unzkey(uint32_t k) {
 __device__ __forceinline__ int lane_rank(unsigned long long m) {  // set bits of m below this lane
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
+
+#ifdef OCC_DBG_TIME  // diagnostic build only: shader cycles per phase of the raster kernel, summed over waves
+__device__ unsigned long long g_dbg_time[16];
+#define OCC_T_DECL unsigned long long t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long t_last = __builtin_amdgcn_s_memtime()
+#define OCC_T(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
+#define OCC_T_FLUSH do { if (lane == 0) { for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_dbg_time[i_], t_acc[i_]); } } while (0)
+#else
+#define OCC_T_DECL do { } while (0)
+#define OCC_T(i) do { } while (0)
+#define OCC_T_FLUSH do { } while (0)
+#endif
 
 #ifndef OCC_RASTER2_WAVES_PER_SIMD
 #define OCC_RASTER2_WAVES_PER_SIMD 3
@@ -68,12 +88,26 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
     const int K = P.K;
     constexpr int kParts = GRAD ? kRecParts : (SOFT ? 5 : 4);  // float4 parts of a record that this variant reads
 
-    __shared__ float4 s_rec[kRecParts * kStgPad];  // staged records, part-major; idle during selection: histograms
+    // staged records (part-major) + pair descriptors; both idle during a selection, whose histograms alias them
+    constexpr int kRecF4 = kRecParts * kStgPad;
+    static_assert(kPairCap == kStg2 * 64 && kPairCap == 2048, "pair map: two 16-byte stores per lane clear it");
+    __shared__ float4 s_pool[kRecF4 + kPairCap / 16];
+    float4* const s_rec = s_pool;
+    uint8_t* const s_flag = reinterpret_cast<uint8_t*>(s_pool + kRecF4);  // pair map: 1 = first pair of a face
+    // selection scratch on top of the same pool: 64 x kSelDw histogram dwords, then seven 64-entry arrays
+    static_assert(sizeof(float4) * (kRecF4 + kPairCap / 16) >= 64 * kSelDw * 4 + 64 * 4 * 8, "selection scratch does not fit");
+    uint32_t* const s_selbase = reinterpret_cast<uint32_t*>(s_pool) + 64 * kSelDw;
+    uint2* const s_sel = reinterpret_cast<uint2*>(s_selbase);            // selection window (low key, shift | 255 = idle)
+    uint32_t* const s_take = s_selbase + 128;
+    uint32_t* const s_lcnt = s_selbase + 192;   // boundary-list fill counts (final selection) ...
+    uint32_t* const s_kmax2 = s_selbase + 192;  // ... or the kept entries' largest key (in-loop compaction): never both
+    // re-accumulated (sum log2(1 - p), sum g_el, sum g_az, count) of the pixels that went through selection
+    float4* const s_acc2 = reinterpret_cast<float4*>(s_selbase + 256);
     __shared__ int s_hit[kStg2];                   // record index of every staged face
     __shared__ uint2 s_box[kStg2];                 // its pixel bbox (xl | yl << 16, xh | yh << 16)
-    __shared__ unsigned short s_desc[kPairCap];    // (staged slot << 6) | pixel of the tile
-    __shared__ uint32_t s_cnt[64], s_kmax[64], s_bnd[64], s_selL[64], s_selSh[64], s_take[64];
-    __shared__ float s_slog[64], s_sge[64], s_sga[64];
+    __shared__ float4 s_acc[kCopies * kAccStride]; // (prod (1 - p_k), sum g_el, sum g_az, count) per copy and pixel
+    __shared__ uint32_t s_akm[kCopies * kAccStride];  // largest stored key per copy and pixel
+    __shared__ uint32_t s_bnd[64];                 // key bound of every pixel
     __shared__ unsigned long long s_hard[64];
     __shared__ float s_xf[kT2], s_yf[kT2];
 
@@ -81,15 +115,17 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
     {
         char* base = reinterpret_cast<char*>(P.ws.lists) + (size_t)blockIdx.x * OCC_LOG_BYTES;
         lg.pay = reinterpret_cast<float4*>(base);
-        lg.key = reinterpret_cast<uint32_t*>(base + (size_t)OCC_LOG_CAP * 16);
-        lg.tag = reinterpret_cast<uint8_t*>(base + (size_t)OCC_LOG_CAP * 20);
+        lg.kt = reinterpret_cast<uint2*>(base + (size_t)OCC_LOG_CAP * 16);
     }
     ciptr offs = as_const(P.ws.offsets);
     const int mq = xcd_slots(P.sc.n_env), MP = 8 * mq;
     const int my_xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;  // steers which queue is drained first only
     int qround = 0;
+    const int myslot = 9 * (lane >> 3) + (lane & 7);  // accumulator slot of the pixel this lane owns
+    OCC_T_DECL;
 
     for (;;) {
+        OCC_T(9);  // previous item's result stores
         int item = -1;
         while (qround < 8) {
             const int qq = (my_xcc + qround) & 7;
@@ -104,6 +140,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             qround += 1;
         }
         if (item < 0) break;
+        OCC_T(0);  // dequeue
         int lo = 0, hi = MP;
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -122,7 +159,6 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
         if (n < 0 || n > span.cap) continue;
         OCC_STAT(0, 1);  // work items
         const float4* __restrict__ recs4 = reinterpret_cast<const float4*>(P.ws.rec + span.base * OCC_REC_STRIDE);
-        const uint4* __restrict__ bbs = reinterpret_cast<const uint4*>(P.ws.rec_bbox) + span.base;
         const uint4* __restrict__ scan = reinterpret_cast<const uint4*>(P.ws.scan) + span.base;
 
         __syncthreads();  // the previous item's readers of the LDS state are done
@@ -131,62 +167,126 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             s_xf[lane] = -1.0f + (2.0f * (float)(S - 1 - (x0t + lane)) + 1.0f) / fS;
             s_yf[lane] = -1.0f + (2.0f * (float)(S - 1 - (y0t + lane)) + 1.0f) / fS;
         }
-        s_cnt[lane] = 0u;
-        s_kmax[lane] = 0u;
+#pragma unroll
+        for (int cpy = 0; cpy < kCopies; ++cpy) {
+            s_acc[cpy * kAccStride + myslot] = make_float4(1.f, 0.f, 0.f, 0.f);
+            s_akm[cpy * kAccStride + myslot] = 0u;
+        }
         s_bnd[lane] = 0xFFFFFFFFu;
-        s_slog[lane] = 0.f;
-        s_sge[lane] = 0.f;
-        s_sga[lane] = 0.f;
         s_hard[lane] = ~0ull;
+        OCC_T(1);  // item decode + state init
         int nlog = 0;               // entries in the wave's log (wave-uniform)
         bool lim_on = false;        // this lane's pixel already holds >= K candidates
         uint32_t bnd = 0xFFFFFFFFu; // key bound of this lane's pixel (copy of s_bnd[lane])
         uint32_t thrB = 0xFFFFFFFFu;      // tile-wide skip key (wave-uniform)
         uint32_t kmin_tile = 0xFFFFFFFFu; // smallest depth key any candidate of this tile can have (chunk boxes)
+        uint32_t kmx_lane = 0u;           // largest key this lane has appended to the log (selection window)
+        // pruning bounds need every pixel's largest stored key: only kept for objects whose scan order is front to
+        // back (occ_sort_kernel, >= kSortMin records) - in mesh order the bounds hardly ever bite
+        const bool dense = n >= kSortMin;
 
         auto touches = [&](uint4 bb) {
             const int rx0 = bb.x & 0xFFFF, ry0 = bb.x >> 16, rx1 = bb.y & 0xFFFF, ry1 = bb.y >> 16;
             return (rx0 <= x0t + kT2 - 1) && (rx1 >= x0t) && (ry0 <= y0t + kT2 - 1) && (ry1 >= y0t);
         };
+        // this lane's pixel: candidates held and their largest key (four copies folded)
+        auto own_count = [&]() {
+            return (int)(s_acc[myslot].w + s_acc[kAccStride + myslot].w + s_acc[2 * kAccStride + myslot].w +
+                         s_acc[3 * kAccStride + myslot].w);
+        };
+        auto own_kmax = [&]() {
+            return max(max(s_akm[myslot], s_akm[kAccStride + myslot]), max(s_akm[2 * kAccStride + myslot], s_akm[3 * kAccStride + myslot]));
+        };
+
+        // Rank of this lane among the (valid) lanes of the wave that hold the same 6-bit pixel tag: lanes of equal rank
+        // have distinct pixels, so a loop over ranks can update per-pixel LDS state with plain loads and stores.
+        // (LDS atomics that collide on an address cost 20 - 60 cycles per lane here; six ballots cost ~40 instructions.)
+        auto same_tag_rank = [&](const uint32_t tag, const bool valid) __attribute__((always_inline)) -> int {
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const bool bit = (tag >> b) & 1u;
+                const unsigned long long mb = __ballot(valid && bit);
+                peers &= bit ? mb : ~mb;
+            }
+            return valid ? (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u)) : 0x7FFFFFFF;
+        };
 
         // ---- exact top-K over the log for every pixel holding more than K entries ---------------------------
-        // Leaves, for those pixels, count / kmax / log-product / tangent sums of their K nearest in the LDS state;
-        // COMPACT also rewrites the log so that it holds exactly the entries still accounted for.
-        auto select_topk = [&](const bool compact) {
+        // Leaves the sums of those pixels' K nearest in s_acc2 (and s_kmax2 when compacting) and returns whether
+        // this lane's pixel was one of them.  COMPACT also rewrites the log so that it holds exactly the entries still
+        // accounted for, and folds the selected sums back into the accumulator copies.
+        auto select_topk = [&](const bool compact) __attribute__((always_inline)) -> bool {
             __syncthreads();
-            uint32_t* hist = reinterpret_cast<uint32_t*>(s_rec);  // 64 pixels x kSelDw dwords (u16 buckets)
-            const int cnt = (int)s_cnt[lane];
+            uint32_t* hist = reinterpret_cast<uint32_t*>(s_pool);  // 64 pixels x kSelDw dwords (u16 buckets)
+            const int cnt = own_count();
             const bool ovf = cnt > K;
             // window start: a candidate's depth is a convex combination of its face's vertex depths, so no key lies
             // below the smallest chunk-box key of the tile - up to rounding, hence the margin of 4096 ulp
             uint32_t L = kmin_tile > 4096u ? kmin_tile - 4096u : 0u;
             int need = K, sh = 0;
             {
-                const uint32_t kmx = s_kmax[lane];
+                uint32_t kmx = kmx_lane;  // largest key in the log: wave maximum of the lanes' own
+#pragma unroll
+                for (int mm = 32; mm >= 1; mm >>= 1) kmx = max(kmx, (uint32_t)__shfl_xor((int)kmx, mm, 64));
                 const uint32_t range = kmx >= L ? kmx - L : 0u;
                 sh = range ? max(0, (32 - __builtin_clz(range)) - kSelBits) : 0;
             }
-            bool done = !ovf, takeall = false;
-            s_selSh[lane] = done ? 255u : (uint32_t)sh;
-            s_selL[lane] = L;
+            // A sweep visits the log in groups of kSweepU rows of 64 entries; the next group's loads are issued before
+            // the current one is processed (two groups = 8 KB in flight per wave: a sweep is pure memory latency)
+            auto load_group = [&](const int e0, uint2 (&kt)[kSweepU]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < kSweepU; ++u) {
+                    const int e = e0 + u * 64 + lane;
+                    kt[u] = e < nlog ? lg.kt[e] : make_uint2(0u, 255u);
+                }
+            };
+            constexpr int kGroup = 64 * kSweepU;
+            // how the boundary bucket [L, L + 2^sh) of an overflowing pixel is resolved in the final sweep
+            enum { kAll = 0, kTies = 1, kList = 2 };
+            int mode = kAll;
+            bool done = !ovf;
+            s_sel[lane] = make_uint2(L, done ? 255u : (uint32_t)sh);
+            OCC_T(10);  // selection: set-up
             while (__ballot(!done)) {
 #pragma unroll
                 for (int i = 0; i < kSelDw; i += 4) reinterpret_cast<uint4*>(hist + lane * kSelDw)[i >> 2] = make_uint4(0u, 0u, 0u, 0u);
                 __syncthreads();
-                for (int e0 = 0; e0 < nlog; e0 += 64) {
-                    const int e = e0 + lane;
-                    if (e < nlog) {
-                        const uint32_t k = lg.key[e];
-                        const int t = lg.tag[e];
-                        const uint32_t shp = s_selSh[t];
-                        if (shp < 32u) {
-                            const uint32_t Lp = s_selL[t];
-                            const uint32_t d = (k - Lp) >> shp;
-                            if (k >= Lp && d < (1u << kSelBits)) atomicAdd(&hist[t * kSelDw + (d >> 1)], 1u << (16 * (d & 1u)));
+                // histogram sweep: order is irrelevant, so every lane takes PAIRS of entries with 16-byte loads,
+                // kHistU of them in flight (8 KB per wave)
+                for (int e0 = 0; e0 < nlog; e0 += 128 * kHistU) {
+                    uint4 q[kHistU];
+#pragma unroll
+                    for (int u = 0; u < kHistU; ++u) {
+                        const int e = e0 + u * 128 + 2 * lane;
+                        q[u] = e + 1 < nlog ? reinterpret_cast<const uint4*>(lg.kt)[e >> 1]
+                                            : (e < nlog ? make_uint4(lg.kt[e].x, lg.kt[e].y, 0u, 255u) : make_uint4(0u, 255u, 0u, 255u));
+                    }
+#pragma unroll
+                    for (int u = 0; u < kHistU; ++u) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const uint32_t k = h ? q[u].z : q[u].x, t = h ? q[u].w : q[u].y;
+                            bool hit = false;
+                            uint32_t d = 0u;
+                            if (t < 64u) {
+                                const uint2 w = s_sel[t];
+                                if (w.y < 32u) {
+                                    d = (k - w.x) >> w.y;
+                                    hit = k >= w.x && d < (1u << kSelBits);
+                                }
+                            }
+                            if (__ballot(hit)) {
+                                const int rk = same_tag_rank(t, hit);
+                                for (int i = 0; __ballot(hit && rk >= i); ++i) {
+                                    if (hit && rk == i) hist[t * kSelDw + (d >> 1)] += 1u << (16 * (d & 1u));
+                                }
+                            }
                         }
                     }
                 }
                 __syncthreads();
+                OCC_T(11);  // selection: histogram sweeps
                 if (!done) {
                     int cum = 0, bstar = (1 << kSelBits) - 1, mstar = 0, cumb = 0;
                     bool found = false;
@@ -201,90 +301,189 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     }
                     need -= cumb;
                     L += (uint32_t)bstar << sh;
-                    if (mstar == need || sh == 0 || !found) {
+                    if (mstar == need || !found) {
                         done = true;
-                        takeall = (mstar == need) || !found;
+                        mode = kAll;  // the whole bucket is kept
+                    } else if (sh == 0) {
+                        done = true;
+                        mode = kTies;  // one key value, more holders than places: first come (log order = scan order)
+                    } else if (!compact && mstar <= kListCap) {
+                        done = true;
+                        mode = kList;  // a handful of entries: the owner lane sorts them out after the final sweep
                     } else {
                         sh = max(0, sh - kSelBits);
                     }
-                    s_selSh[lane] = done ? 255u : (uint32_t)sh;
-                    s_selL[lane] = L;
+                    s_sel[lane] = make_uint2(L, done ? 255u : (uint32_t)sh);
                 }
                 __syncthreads();
+                OCC_T(12);  // selection: bucket scans
             }
             // final window of an overflowing pixel: keys < L are kept, of the bucket [L, L + 2^sh) `need` more
-            // (all of it when takeall; exact-key ties otherwise, served in log order = scan order)
-            s_selL[lane] = L;
-            s_selSh[lane] = ovf ? (uint32_t)sh : 255u;
-            s_take[lane] = takeall ? 0x7FFFFFFFu : (uint32_t)max(need, 0);
-            if (ovf) {
-                s_cnt[lane] = 0u;
-                s_kmax[lane] = 0u;
-                s_slog[lane] = 0.f;
-                s_sge[lane] = 0.f;
-                s_sga[lane] = 0.f;
-            }
+            s_sel[lane] = make_uint2(L, ovf ? (uint32_t)sh | ((uint32_t)mode << 8) : 255u);
+            s_take[lane] = mode == kAll ? 0x7FFFFFFFu : (uint32_t)max(need, 0);
+            s_lcnt[lane] = 0u;  // kList: entries collected so far / compaction: largest kept key
+            s_acc2[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint2* blist = reinterpret_cast<uint2*>(s_pool);  // kList: (key, log index) x kListCap per pixel (histograms are done)
             __syncthreads();
             int wr = 0;
-            for (int e0 = 0; e0 < nlog; e0 += 64) {
-                const int e = e0 + lane;
-                bool keep = false, readd = false;
-                uint32_t k = 0u;
-                int t = 0;
-                float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < nlog) {
-                    k = lg.key[e];
-                    t = lg.tag[e];
-                    const uint32_t shp = s_selSh[t];
-                    if (shp >= 32u) {
-                        keep = true;  // pixel not overflowing: its entries stay, its sums are already right
-                    } else {
-                        const uint32_t Lp = s_selL[t];
-                        if (k < Lp) {
-                            readd = true;
-                        } else if (((k - Lp) >> shp) == 0u) {
-                            // atomicSub returns the old value: the first `take` arrivals are kept
-                            readd = (int)atomicSub(&s_take[t], 1u) > 0;
+            auto settle = [&](const int e0, const uint2 (&kt)[kSweepU]) __attribute__((always_inline)) {
+                uint32_t keepm = 0u, readdm = 0u;  // per-row decisions of this lane, bit u
+                float4 pv[kSweepU];
+#pragma unroll
+                for (int u = 0; u < kSweepU; ++u) {  // decisions in log order (ties are served first come)
+                    if (kt[u].y < 64u) {
+                        const uint2 w = s_sel[kt[u].y];
+                        const uint32_t shp = w.y & 255u;
+                        if (shp >= 32u) {
+                            keepm |= 1u << u;  // pixel not overflowing: its entries stay, its sums are already right
+                        } else {
+                            bool r = false;
+                            if (kt[u].x < w.x) {
+                                r = true;
+                            } else if (((kt[u].x - w.x) >> shp) == 0u) {
+                                if ((w.y >> 8) == (uint32_t)kList) {
+                                    const uint32_t sl = atomicAdd(&s_lcnt[kt[u].y], 1u);
+                                    if (sl < (uint32_t)kListCap) blist[kt[u].y * kListCap + sl] = make_uint2(kt[u].x, (uint32_t)(e0 + u * 64 + lane));
+                                } else {
+                                    // atomicSub returns the old value: the first `take` arrivals are kept
+                                    r = (int)atomicSub(&s_take[kt[u].y], 1u) > 0;
+                                }
+                            }
+                            if (r) {
+                                readdm |= 1u << u;
+                                keepm |= 1u << u;
+                            }
                         }
-                        keep = readd;
-                    }
-                    if (readd || (compact && keep)) pv = lg.pay[e];
-                }
-                if (readd) {
-                    atomicAdd(&s_cnt[t], 1u);
-                    atomicMax(&s_kmax[t], k);
-                    atomicAdd(&s_slog[t], pv.x);
-                    if (GRAD) {
-                        atomicAdd(&s_sge[t], pv.y);
-                        atomicAdd(&s_sga[t], pv.z);
                     }
                 }
-                if (compact) {
-                    const unsigned long long m = __ballot(keep);
-                    if (keep) {
-                        const int w = wr + lane_rank(m);  // w <= e: never overtakes the reads of a later iteration
-                        lg.key[w] = k;
-                        lg.tag[w] = (uint8_t)t;
-                        lg.pay[w] = pv;
-                    }
-                    wr += __popcll(m);
+#pragma unroll
+                for (int u = 0; u < kSweepU; ++u) {
+                    const int e = e0 + u * 64 + lane;
+                    pv[u] = (((readdm | (compact ? keepm : 0u)) >> u) & 1u) ? lg.pay[e] : make_float4(1.f, 0.f, 0.f, 0.f);
                 }
-            }
-            if (compact) {
-                nlog = wr;
-                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the rewritten log is in place before it grows again
+#pragma unroll
+                for (int u = 0; u < kSweepU; ++u) {
+                    const bool rd = (readdm >> u) & 1u;
+                    if (__ballot(rd)) {
+                        // product of the kept (1 - p_k) in the log domain: exp2(sum log2); log2(0) = -inf -> 0
+                        const float lq = __builtin_amdgcn_logf(pv[u].x);
+                        const uint32_t t = kt[u].y & 63u;
+                        const int rk = same_tag_rank(t, rd);
+                        for (int i = 0; __ballot(rd && rk >= i); ++i) {
+                            if (rd && rk == i) {
+                                float4 a = s_acc2[t];
+                                a.x += lq;
+                                if (GRAD) {
+                                    a.y += pv[u].y;
+                                    a.z += pv[u].z;
+                                }
+                                a.w += 1.0f;
+                                s_acc2[t] = a;
+                                if (compact) s_kmax2[t] = max(s_kmax2[t], kt[u].x);
+                            }
+                        }
+                    }
+                    if (compact) {
+                        const bool kp = (keepm >> u) & 1u;
+                        const unsigned long long m = __ballot(kp);
+                        if (kp) {
+                            const int w = wr + lane_rank(m);  // w <= e: never overtakes the reads of a later group
+                            lg.kt[w] = kt[u];
+                            lg.pay[w] = pv[u];
+                        }
+                        wr += __popcll(m);
+                    }
+                }
+            };
+            {
+                uint2 ka[kSweepU];
+                for (int e0 = 0; e0 < nlog; e0 += kGroup) {
+                    load_group(e0, ka);
+                    settle(e0, ka);
+                }
             }
             __syncthreads();
+            OCC_T(13);  // selection: final sweep
+            if (!compact && __ballot(mode == kList)) {
+                // the owner lane picks the `need` nearest of its <= kListCap boundary entries by (key, log index) and
+                // adds them to what the sweep accumulated
+                const int nb = (mode == kList) ? min((int)s_lcnt[lane], kListCap) : 0;
+                uint2 be[kListCap];
+#pragma unroll
+                for (int i = 0; i < kListCap; ++i) be[i] = i < nb ? blist[lane * kListCap + i] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+                uint32_t takem = 0u;
+#pragma unroll
+                for (int i = 0; i < kListCap; ++i) {
+                    int rank = 0;
+#pragma unroll
+                    for (int jj = 0; jj < kListCap; ++jj)
+                        rank += (be[jj].x < be[i].x || (be[jj].x == be[i].x && be[jj].y < be[i].y)) ? 1 : 0;
+                    if (i < nb && rank < need) takem |= 1u << i;
+                }
+                float4 pv[kListCap];
+#pragma unroll
+                for (int i = 0; i < kListCap; ++i) pv[i] = ((takem >> i) & 1u) ? lg.pay[be[i].y] : make_float4(1.f, 0.f, 0.f, 0.f);
+                float4 a2 = s_acc2[lane];
+                float sl = a2.x, se = a2.y, sa = a2.z;
+#pragma unroll
+                for (int i = 0; i < kListCap; ++i) {
+                    if ((takem >> i) & 1u) {
+                        sl += __builtin_amdgcn_logf(pv[i].x);
+                        se += pv[i].y;
+                        sa += pv[i].z;
+                    }
+                }
+                s_acc2[lane] = make_float4(sl, se, sa, a2.w);
+            }
+            OCC_T(14);  // selection: boundary lists
+            if (compact) {
+                nlog = wr;
+                if (ovf) {  // the selected sums become the pixel's accumulated state (copy 0; the others empty)
+                    const float4 a2 = s_acc2[lane];
+                    s_acc[myslot] = make_float4(__builtin_amdgcn_exp2f(a2.x), a2.y, a2.z, a2.w);
+                    s_akm[myslot] = s_kmax2[lane];
+#pragma unroll
+                    for (int cpy = 1; cpy < kCopies; ++cpy) {
+                        s_acc[cpy * kAccStride + myslot] = make_float4(1.f, 0.f, 0.f, 0.f);
+                        s_akm[cpy * kAccStride + myslot] = 0u;
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the rewritten log is in place before it grows again
+                __syncthreads();
+            }
+            return ovf;
         };
 
         // ---- one staged batch: records -> LDS, pair expansion, evaluation rounds ------------------------------
         int nst = 0;  // staged faces (wave-uniform)
-        auto process_batch = [&]() {
-            __syncthreads();
-            for (int idx = lane; idx < nst * kRecParts; idx += 64) {
-                const int k = idx >> 3, part = idx & 7;
-                if (part < kParts) s_rec[part * kStgPad + k] = recs4[(size_t)s_hit[k] * kRecParts + part];
+        // records of the staged faces -> LDS (part-major).  Lane i of a group of 8 fetches part i of one record: the 8
+        // loads of a record are one 128-byte line.  kStg2 * 8 / 64 = 4 loads per lane, issued together.
+        constexpr int kStageLoads = kStg2 * kRecParts / 64;
+        auto stage_issue = [&](float4 (&r)[kStageLoads]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < kStageLoads; ++i) {
+                const int idx = lane + 64 * i, k = idx >> 3, part = idx & 7;
+                r[i] = (idx < nst * kRecParts && part < kParts) ? recs4[(size_t)s_hit[k] * kRecParts + part] : make_float4(0, 0, 0, 0);
             }
+        };
+        auto stage_commit = [&](const float4 (&r)[kStageLoads]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < kStageLoads; ++i) {
+                const int idx = lane + 64 * i, k = idx >> 3, part = idx & 7;
+                if (idx < nst * kRecParts && part < kParts) s_rec[part * kStgPad + k] = r[i];
+            }
+        };
+        auto stage_records = [&]() __attribute__((always_inline)) {
+            float4 r[kStageLoads];
+            stage_issue(r);
+            stage_commit(r);
+        };
+        auto process_batch = [&]() {
+            OCC_T(2);  // scan (chunk boxes, rows, hit lists)
+            __syncthreads();
+            // the record loads fly while the pair counts, their prefix sum and the first window's descriptors are made
+            float4 rstage[kStageLoads];
+            stage_issue(rstage);
             // pixels of this lane's face inside the tile: pair count, prefix sum over the staged faces
             int c = 0, cx0 = 0, cy0 = 0, cw = 1;
             if (lane < nst) {
@@ -296,78 +495,91 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 c = max(cw, 0) * max(cy1 - cy0 + 1, 0);
                 cw = max(cw, 1);
             }
-            int incl = c;
+            // exclusive prefix sum of the pair counts (<= 64 each: 7 bits) from one ballot per bit - no LDS round trips
+            int pre = 0, ptot = 0;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int t = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += t;
+            for (int b = 0; b < 7; ++b) {
+                const unsigned long long mb = __ballot((c >> b) & 1);
+                pre += lane_rank(mb) << b;
+                ptot += __popcll(mb) << b;
             }
-            const int pre = incl - c;
-            const int ptot = __shfl(incl, 63, 64);
-            const int cmax = wave_max_i(c);
+            // Pair p of the batch belongs to the face with the largest pre <= p.  Instead of writing one descriptor per
+            // pair, every face marks its FIRST pair in a byte map; a round ballots its 64 flags and a lane's face is
+            // the running face count plus the marks at or below it.  (pre, clip origin, width, 2^15 / width) of every
+            // face replace its bbox in s_box.
+            auto mark_pairs = [&]() __attribute__((always_inline)) {
+                const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+                reinterpret_cast<uint4*>(s_flag)[lane] = z4;
+                reinterpret_cast<uint4*>(s_flag)[lane + 64] = z4;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if (lane < nst) {
+                    const uint32_t inv15 = (32768u + (uint32_t)cw - 1u) / (uint32_t)cw;
+                    s_box[lane] = make_uint2((uint32_t)pre, (uint32_t)(cx0 - x0t) | ((uint32_t)(cy0 - y0t) << 3) | ((uint32_t)(cw - 1) << 6) | (inv15 << 16));
+                    if (lane > 0) s_flag[pre] = 1;
+                }
+            };
             OCC_STAT(1, 1);      // staged batches
             OCC_STAT(2, nst);    // staged records = (face, tile) pairs
             OCC_STAT(3, (ptot + 63) >> 6);  // evaluation rounds
-            for (int wbase = 0; wbase < ptot; wbase += kPairCap) {
-                __syncthreads();  // previous window's descriptors consumed; records staged
-                {
-                    int xx = cx0 - x0t, yy = cy0 - y0t;
-                    const int xb = xx, xe = xx + cw;
-                    for (int j = 0; j < cmax; ++j) {
-                        if (j < c) {
-                            const int p = pre + j - wbase;
-                            if ((unsigned)p < (unsigned)kPairCap) s_desc[p] = (unsigned short)((lane << 6) | (yy << 3) | xx);
-                            xx += 1;
-                            if (xx == xe) {
-                                xx = xb;
-                                yy += 1;
-                            }
-                        }
-                    }
-                }
+            {
+                OCC_T(3);  // pair counts
+                mark_pairs();
+                stage_commit(rstage);
                 __syncthreads();
-                const int wend = min(ptot - wbase, kPairCap);
-                for (int p0 = 0; p0 < wend; p0 += 64) {
-                    if (SOFT && nlog + 64 > OCC_LOG_CAP) {
-                        // rare: the log is full -> keep every overflowing pixel's K nearest, go on with tighter bounds
-                        select_topk(true);
-                        const int cn = (int)s_cnt[lane];
-                        if (cn >= K) {
-                            lim_on = true;
-                            bnd = min(bnd, s_kmax[lane]);
-                            s_bnd[lane] = bnd;
-                        }
-                        // the histograms lived in s_rec: stage this batch's records again
-                        __syncthreads();
-                        for (int idx = lane; idx < nst * kRecParts; idx += 64) {
-                            const int k = idx >> 3, part = idx & 7;
-                            if (part < kParts) s_rec[part * kStgPad + k] = recs4[(size_t)s_hit[k] * kRecParts + part];
-                        }
-                        __syncthreads();
+                OCC_T(4);  // pair map
+                if (SOFT && nlog + ptot > OCC_LOG_CAP) {
+                    // rare: the log could fill up inside this batch -> keep every overflowing pixel's K nearest,
+                    // compact the log, go on with tighter bounds
+                    select_topk(true);
+                    if (dense && own_count() >= K) {
+                        lim_on = true;
+                        bnd = min(bnd, own_kmax());
+                        s_bnd[lane] = bnd;
                     }
-                    const bool live = p0 + lane < wend;
-                    const uint32_t d = live ? s_desc[p0 + lane] : 0u;
-                    const int f = d >> 6, pix = d & 63;
+                    // the histograms lived on top of the records and the pair map: put both back
+                    stage_records();
+                    mark_pairs();
+                    __syncthreads();
+                    OCC_T(7);  // in-loop compaction
+                }
+                int fbase = 0;  // face of the pair just before this round
+#ifdef OCC_DBG2_NO_EVAL  // timing experiment only
+                if (ptot > 0) fbase = -1;
+#endif
+                for (int p0 = 0; p0 < ptot && fbase >= 0; p0 += 64) {
+                    const int nlive = min(64, ptot - p0);
+                    const bool live = lane < nlive;
+                    const bool mark = live && s_flag[p0 + lane] != 0;
+                    const unsigned long long mk = __ballot(mark);
+                    const int f = live ? fbase + lane_rank(mk) + (mark ? 1 : 0) : 0;
+                    fbase += __popcll(mk);
+                    const uint2 fg = s_box[f];
+                    const uint32_t jj = live ? (uint32_t)(p0 + lane) - fg.x : 0u;
+                    const uint32_t wq = (jj * (fg.y >> 16)) >> 15;  // jj / width (exact for jj < 64, width <= 8)
+                    const uint32_t px_ = (fg.y & 7u) + (jj - wq * (((fg.y >> 6) & 7u) + 1u)), py_ = ((fg.y >> 3) & 7u) + wq;
+                    const uint32_t d = (py_ << 3) | px_;
+                    const int pix = (int)d;
                     const int j = s_hit[f];
                     const float xf = s_xf[d & 7], yf = s_yf[(d >> 3) & 7];
                     const float4* rs = &s_rec[f];
                     Cand c1;
-                    eval_face<SOFT, GRAD>(rs[0], rs[kStgPad], rs[2 * kStgPad], rs[3 * kStgPad],
-                                          kParts > 4 ? rs[4 * kStgPad] : make_float4(0, 0, 0, 0),
-                                          kParts > 5 ? rs[5 * kStgPad] : make_float4(0, 0, 0, 0),
-                                          kParts > 5 ? rs[6 * kStgPad] : make_float4(0, 0, 0, 0),
-                                          kParts > 5 ? rs[7 * kStgPad] : make_float4(0, 0, 0, 0), xf, yf, c1);
+                    eval_face<SOFT, GRAD, false>(rs[0], rs[kStgPad], rs[2 * kStgPad], rs[3 * kStgPad],
+                                                 kParts > 4 ? rs[4 * kStgPad] : make_float4(0, 0, 0, 0),
+                                                 kParts > 5 ? rs[5 * kStgPad] : make_float4(0, 0, 0, 0),
+                                                 kParts > 5 ? rs[6 * kStgPad] : make_float4(0, 0, 0, 0),
+                                                 kParts > 5 ? rs[7 * kStgPad] : make_float4(0, 0, 0, 0), xf, yf, c1);
                     const int flags = live ? __float_as_int(rs[2 * kStgPad].z) : 0;
-                    bool emit = live;
                     // Clipped quad split in two: only one half may enter a pixel's list.  Both halves'
                     // lanes look at both halves; the SECOND half's lane emits the winner when both are candidates,
-                    // a half whose partner is no candidate at this pixel emits itself.
+                    // a half whose partner is no candidate at this pixel emits itself.  (A partner that the pruning
+                    // bounds kept out of the batch has no lane: it lies beyond every pixel's K nearest anyway.)
                     if (__ballot(flags & (FLAG_PAIR_FIRST | FLAG_PAIR_SECOND))) {
                         const bool is_first = (flags & FLAG_PAIR_FIRST) != 0, is_second = (flags & FLAG_PAIR_SECOND) != 0;
                         if ((is_first && j + 1 < n) || (is_second && j >= 1)) {
                             const float4* r1 = recs4 + (size_t)(is_first ? j + 1 : j - 1) * kRecParts;
                             Cand cp;
-                            eval_face<SOFT, GRAD>(OCC_REC_LOAD(r1, kParts), xf, yf, cp);
+                            eval_face<SOFT, GRAD, false>(OCC_REC_LOAD(r1, kParts), xf, yf, cp);
                             if (is_first) {
                                 if (cp.cand) c1.cand = false;  // the second half's lane decides
                             } else if (cp.cand && c1.cand) {
@@ -388,35 +600,52 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): leave no load pending across the hot loop
                     }
                     if (HARD) {
-                        if (emit && c1.inside)
+                        if (live && c1.inside)
                             atomicMin(&s_hard[pix], ((unsigned long long)zkey(c1.zh) << 32) | (unsigned)j);
                     }
                     if (SOFT) {
                         const uint32_t key = zkey(c1.z);
-                        const bool acc = emit && c1.cand && key < s_bnd[pix];
+                        const bool acc = live && c1.cand && (!dense || key < s_bnd[pix]);
                         const unsigned long long m = __ballot(acc);
                         if (m) {
+#ifndef OCC_DBG2_NO_LOG  // timing experiment only
                             if (acc) {
                                 const int e = nlog + lane_rank(m);
-                                // log-domain product: prod(1 - p_k) = exp2(sum log2(1 - p_k)); log2(0) = -inf -> prod 0
-                                const float lq = __builtin_amdgcn_logf(c1.q);
-                                lg.key[e] = key;
-                                lg.tag[e] = (uint8_t)pix;
-                                lg.pay[e] = make_float4(lq, c1.ge, c1.ga, 0.f);
-                                atomicAdd(&s_cnt[pix], 1u);
-                                atomicMax(&s_kmax[pix], key);
-                                atomicAdd(&s_slog[pix], lq);
-                                if (GRAD) {
-                                    atomicAdd(&s_sge[pix], c1.ge);
-                                    atomicAdd(&s_sga[pix], c1.ga);
+                                lg.kt[e] = make_uint2(key, (uint32_t)pix);
+                                lg.pay[e] = make_float4(c1.q, c1.ge, c1.ga, 0.f);
+                            }
+#endif
+                            nlog += __popcll(m);
+#ifndef OCC_DBG2_NO_ATOM  // timing experiment only
+                            // accumulate: plain read-modify-write in sub-passes of four consecutive staged faces
+                            const int f_first = __builtin_amdgcn_readfirstlane(f);
+                            const int f_last = __builtin_amdgcn_readlane(f, nlive - 1);
+                            const int slot = (f & 3) * kAccStride + 9 * (pix >> 3) + (pix & 7);
+                            const int grp = (f - f_first) >> 2;
+                            const int nsub = ((f_last - f_first) >> 2) + 1;
+                            for (int sp = 0; sp < nsub; ++sp) {
+                                if (acc && grp == sp) {
+                                    float4 a = s_acc[slot];
+                                    a.x *= c1.q;
+                                    if (GRAD) {
+                                        a.y += c1.ge;
+                                        a.z += c1.ga;
+                                    }
+                                    a.w += 1.0f;
+                                    s_acc[slot] = a;
+                                    if (dense) s_akm[slot] = max(s_akm[slot], key);
                                 }
                             }
-                            nlog += __popcll(m);
+                            if (acc) kmx_lane = max(kmx_lane, key);
+#else
+                            asm volatile("" ::"v"(c1.q), "v"(c1.ge), "v"(c1.ga));
+#endif
                         }
                     }
                 }
             }
             __syncthreads();
+            OCC_T(5);  // evaluation rounds
             nst = 0;
             // Front-to-back pruning (SURVEY A.4 keeps the K smallest depths): once a pixel holds >= K candidates its
             // largest stored key bounds its K-th nearest from above, later candidates at or beyond it are dropped
@@ -424,9 +653,9 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             // nearest vertex lies beyond every bound are skipped.
             uint32_t bound = 0xFFFFFFFFu;
             if (SOFT) {
-                if (!lim_on && (int)s_cnt[lane] >= K) {
+                if (dense && !lim_on && own_count() >= K) {
                     lim_on = true;
-                    bnd = min(bnd, s_kmax[lane]);
+                    bnd = min(bnd, own_kmax());
                     s_bnd[lane] = bnd;
                 }
                 bound = bnd;
@@ -438,6 +667,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #pragma unroll
             for (int mm = 32; mm >= 1; mm >>= 1) bound = max(bound, (uint32_t)__shfl_xor((int)bound, mm, 64));
             thrB = (uint32_t)__builtin_amdgcn_readfirstlane((int)bound);
+            OCC_T(6);  // pruning bounds
         };
 
         // ---- two-level scan: chunk boxes -> candidate chunks -> their rows (as in occ_raster.hpp) ----------------
@@ -463,60 +693,81 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             cmask &= cmask - 1;
             return cwin + bit;
         };
-        int c = next_chunk();
-        uint4 bb_cur = kEmptyBox;
+        int c = next_chunk(), cn = -1;
+        uint4 bb_cur = kEmptyBox, bb_nxt = kEmptyBox;
         if (c >= 0 && c * 64 + lane < n) bb_cur = scan[c * 64 + lane];
-        while (c >= 0) {
-            const int cn = next_chunk();
-            uint4 bb_nxt = kEmptyBox;
-            if (cn >= 0 && cn * 64 + lane < n) bb_nxt = scan[cn * 64 + lane];
-            const bool hit = touches(bb_cur) && bb_cur.z < thrB;
-            unsigned long long m = __ballot(hit);
-            OCC_STAT(5, 1);  // chunk rows scanned
-            while (m) {  // a chunk may hold more hits than the staging buffer has room for
-                const int room = kStg2 - nst;
-                const int cnt = __popcll(m);
-                const int rank = lane_rank(m);
-                const bool mine = (m >> lane) & 1ull;
-                if (mine && rank < room) {
-                    s_hit[nst + rank] = (int)bb_cur.w;
-                    s_box[nst + rank] = make_uint2(bb_cur.x, bb_cur.y);
+        unsigned long long m = 0;  // hits of row c not yet staged
+        bool opened = false;       // row c has been balloted (and the next row's boxes requested)
+        for (;;) {
+            while (nst < kStg2 && c >= 0) {
+                if (!opened) {
+                    cn = next_chunk();  // the next candidate chunk's row is fetched while this one is worked on
+                    bb_nxt = kEmptyBox;
+                    if (cn >= 0 && cn * 64 + lane < n) bb_nxt = scan[cn * 64 + lane];
+                    m = __ballot(touches(bb_cur) && bb_cur.z < thrB);
+                    opened = true;
+                    OCC_STAT(5, 1);  // chunk rows scanned
                 }
-                if (cnt <= room) {
-                    nst += cnt;
-                    m = 0;
-                } else {
-                    nst = kStg2;
-                    m = __ballot(mine && rank >= room);
-                    process_batch();
+                if (m) {  // a row may hold more hits than the staging buffer has room for
+                    const int room = kStg2 - nst;
+                    const int cnt = __popcll(m);
+                    const int rank = lane_rank(m);
+                    const bool mine = (m >> lane) & 1ull;
+                    if (mine && rank < room) {
+                        s_hit[nst + rank] = (int)bb_cur.w;
+                        s_box[nst + rank] = make_uint2(bb_cur.x, bb_cur.y);
+                    }
+                    nst += min(cnt, room);
+                    m = cnt <= room ? 0ull : __ballot(mine && rank >= room);
+                }
+                if (!m) {
+                    c = cn;
+                    bb_cur = bb_nxt;
+                    opened = false;
                 }
             }
-            c = cn;
-            bb_cur = bb_nxt;
+            if (nst == 0) break;
+            process_batch();
         }
-        if (nst > 0) process_batch();
+        OCC_T(2);
 
         // ---- per-pixel results (lane = pixel) ---------------------------------------------------------------------
         const size_t opix = ((size_t)eo * S + yi) * S + xi;
         if (SOFT) {
             __syncthreads();
-            const bool ovf = (int)s_cnt[lane] > K;
+            const bool ovf = own_count() > K;
 #ifdef OCC_DBG_STATS
             {
-                const int cw_ = (int)wave_sum((float)s_cnt[lane]);
-                const int co_ = (int)wave_sum(ovf ? (float)s_cnt[lane] : 0.f);
+                const int cw_ = (int)wave_sum((float)own_count());
+                const int co_ = (int)wave_sum(ovf ? (float)own_count() : 0.f);
                 OCC_STAT(4, cw_);                    // candidates accounted for
                 OCC_STAT(6, co_);                    // ... of which in pixels that need selection
                 OCC_STAT(7, __ballot(ovf) ? 1 : 0);  // items with at least one such pixel
             }
 #endif
-            if (__ballot(ovf)) select_topk(false);  // more than K candidates: keep the K nearest in z, SURVEY A.4
-            const float prod = __builtin_amdgcn_exp2f(s_slog[lane]);
+            bool selected = false;
+#ifndef OCC_DBG2_NO_SEL  // timing experiment only
+            if (__ballot(ovf)) selected = select_topk(false);  // more than K candidates: keep the K nearest in z, A.4
+#endif
+            OCC_T(8);  // final selection
+            float prod, sge, sga;
+            if (selected) {
+                const float4 a2 = s_acc2[lane];
+                prod = __builtin_amdgcn_exp2f(a2.x);
+                sge = a2.y;
+                sga = a2.z;
+            } else {  // fold the four copies in a fixed order
+                const float4 a0 = s_acc[myslot], a1 = s_acc[kAccStride + myslot], a2 = s_acc[2 * kAccStride + myslot],
+                             a3 = s_acc[3 * kAccStride + myslot];
+                prod = (a0.x * a1.x) * (a2.x * a3.x);
+                sge = (a0.y + a1.y) + (a2.y + a3.y);
+                sga = (a0.z + a1.z) + (a2.z + a3.z);
+            }
             P.ws.obj_alpha[opix] = 1.0f - prod;
             if (GRAD) {
                 // d alpha/d theta = -(A/sigma) * sum_k p_k d(d_k)/d theta   
                 const float coef = -prod * kInvSigma;
-                reinterpret_cast<float2*>(P.ws.obj_grad)[opix] = make_float2(coef * s_sge[lane], coef * s_sga[lane]);
+                reinterpret_cast<float2*>(P.ws.obj_grad)[opix] = make_float2(coef * sge, coef * sga);
             }
         }
         if (HARD) {
@@ -526,4 +777,5 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             P.ws.obj_hrec[opix] = any ? (int)(uint32_t)h : -1;
         }
     }
+    OCC_T_FLUSH;
 }

@@ -59,9 +59,9 @@ class OcclusionEngine:
         self.N = int(n_env)
         self.S = int(img_size)
         self.K = int(faces_per_pixel)
-        # persistent waves per CU of the raster kernel: what its LDS / VGPR budget admits (occ_raster2_kernel: 14 KB of
-        # LDS per wave -> 11; the round-1 kernel, OCC_RASTER=1: 20)
-        default_wpc = 20 if os.environ.get("OCC_RASTER", "")[:1] == "1" else 11
+        # persistent waves per CU of the raster kernel: what its LDS / VGPR budget admits (occ_raster2_kernel: 13.3 KB
+        # of LDS and <= 168 VGPRs per wave -> 12; the round-1 kernel, OCC_RASTER=1: 20)
+        default_wpc = 20 if os.environ.get("OCC_RASTER", "")[:1] == "1" else 12
         self.waves_per_cu = int(waves_per_cu or os.environ.get("OCC_WAVES_PER_CU", default_wpc))
         d = self.device
         f32 = dict(dtype=torch.float32, device=d)

@@ -50,9 +50,9 @@ _LIB = None
 def lib() -> ctypes.CDLL:
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liborc.so")
+        so = os.environ.get("ORC_LIB") or os.path.join(_HERE, "liborc.so")  # ORC_LIB: the sanitizer build (tests)
         if not os.path.exists(so):
-            subprocess.check_call(["make", "-s", "-C", _HERE])
+            subprocess.check_call(["make", "-s", "-C", _HERE] + (["asan"] if so.endswith("_asan.so") else []))
         _LIB = ctypes.CDLL(so)
     return _LIB
 

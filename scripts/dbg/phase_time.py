@@ -1,0 +1,32 @@
+"""Diagnostic (GPU box): shader cycles per phase of occ_raster2_kernel from an OCC_DBG_TIME build.
+   OCC_HIP_LIB=build/dbg2/libocc_time.so python scripts/dbg/phase_time.py [envs]"""
+import ctypes, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from tests.parity_utils import make_case
+from occlusionenv_amd.engine import OcclusionEngine
+from occlusionenv_amd import _native as nat
+lib = nat.load()
+lib.occ_debug_time.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+names = ["dequeue", "decode+init", "scan", "stage+count", "expand", "rounds", "bounds", "compaction(rest)", "final select(rest)", "result stores", "sel:setup", "sel:hist sweeps", "sel:bucket scans", "sel:final sweep", "sel:lists", "-"]
+for mesh, img in [("synthetic", 128), ("mixed", 128), ("teapot", 128)]:
+    case = make_case(N, 11, mesh)
+    eng = OcclusionEngine(case["pool"], N, img)
+    eng.set_scene(list(range(N)), case["mesh_ids"], case["offsets"])
+    eng.reset_render(None, 4.0, case["az"], 0.0)
+    a = case["actions"].cuda().requires_grad_(True)
+    eng.step(a)
+    torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 16)()
+    lib.occ_debug_time(buf)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    eng.step(case["actions"].cuda().requires_grad_(True))
+    ev1.record()
+    torch.cuda.synchronize()
+    lib.occ_debug_time(buf)
+    tot = float(sum(buf[:16]))
+    print(mesh, img, "N", N, "step %.2f ms; wave-cycles %.3e:" % (ev0.elapsed_time(ev1), tot),
+          "  ".join("%s %.1f%%" % (n, 100.0 * buf[i] / tot) for i, n in enumerate(names)), flush=True)
+    del eng

@@ -18,11 +18,16 @@ unexplained fails the test.  Explained pixels are few (bounded below), get weigh
 (OccScene.pix_weight / OracleEnv.pixel_weight) and loss, reward and gradient are then compared at full tolerance
 over all remaining pixels.
 
-ACTION GRADIENT.  d reward / d action is a sum of ~1e6 signed fp32 terms; when it nearly cancels (|g| << its typical
-0.1 - 1) the fp32 round-off of EITHER implementation exceeds 1e-4 of the result (measured against the oracle's f64
-build: the f32 oracle itself is off by 1e-4 ... 1e-3 of |g| in those cases, the HIP path by 0.3x ... 2.3x that).  So:
-relative L2 <= 1e-4 against the f32 oracle, or else the f64 build of the oracle arbitrates: the HIP gradient must be
-within 1e-4 of the f64 gradient or no farther from it than 3x the f32 oracle is.
+ACTION GRADIENT.  d reward / d action is a sum of ~1e5 signed fp32 per-pixel terms (2 I dI/d alpha_o * d alpha_o/d theta,
+each itself -(A/sigma) * a sum of ~100 signed terms).  When the pixel terms nearly cancel (|g| is 1/30 ... 1/200 of
+their L1 mass M in a fair share of scenes) no fp32 evaluation can deliver 1e-4 of the RESULT: measured against the
+oracle's f64 build, the f32 oracle (torch autograd + the C backward) is off by 1 ... 180 eps*M and the HIP path by
+2 ... 155 eps*M (eps = 2^-24; gpurun_out/r2e/mass.log, both raster kernels alike).  Criterion: relative L2 <= 1e-4
+against the f32 oracle; where that fails, the f64 build arbitrates with the fp32 noise floor of this very sum:
+    |g_hip - g_f64| <= 1e-4 |g_f64| + 256 eps M,
+M = the L1 mass of the per-pixel terms, pushed through |J| / objectMass like the gradient itself, computed from the
+engine's per-object alpha / d alpha planes (recomposing the NET sum from the same planes reproduces the engine's
+gradient to 1e-8, so the planes are what the gradient is made of).
 """
 from __future__ import annotations
 
@@ -43,6 +48,7 @@ TPAIR_REL = 1e-4    # |d1 - d2| <= TPAIR_REL * max(d): the halves of a z-clipped
 TEDGE = 5e-7        # pixel centre within this (NDC units, ~8 ulp of a coordinate) of a face edge: inside test can flip
 TAREA = 2e-9        # |signed area - kEpsilon(1e-8)| <= TAREA: the face is visible / culled by a hair
 TTEXEL = 1e-3       # barycentric * R within this of a texel-cell boundary
+GRAD_NOISE_ULPS = 256.0  # fp32 noise floor of the action gradient, in units of eps * (L1 mass of its pixel terms)
 TEAPOT = os.path.join(ROOT, "data", "teapot.obj")
 
 
@@ -97,7 +103,12 @@ def run_engine(case, img, n_env=None, faces_per_pixel=100, radius=4.0, pixel_wei
     obs, reward, done, fs, loss = eng.step(a)
     reward.sum().backward()
     eng.check_status()
-    out = dict(engine=eng, obs0=obs0.cpu(), loss0=loss0.cpu(), fs0=fs0.cpu(), alphas0=alphas0.cpu(), obs=obs.cpu(),
+    from occlusionenv_amd import _native as nat
+    S = img
+    # what the gradient is made of (gradient_mass): per-object d alpha / d(el, az) planes, action Jacobian, objectMass
+    og = eng._ws_tensors["obj_grad"].view(torch.float32)[: n * 3 * S * S * 2].view(n, 3, S, S, 2).cpu().clone()
+    jac = eng.cam[:, nat.C_J:nat.C_J + 4].cpu().reshape(n, 2, 2).clone()
+    out = dict(engine=eng, obj_grad=og, jac=jac, object_mass=eng.object_mass.cpu().clone(), obs0=obs0.cpu(), loss0=loss0.cpu(), fs0=fs0.cpu(), alphas0=alphas0.cpu(), obs=obs.cpu(),
                reward=reward.detach().cpu(), done=done.cpu(), fs=fs.cpu(), loss=loss.cpu(), grad=a.grad.cpu(),
                alphas=eng.alphas.cpu(), campos=eng.camera_position.cpu())
     if render_too:  # OcclusionEnv.render() at the camera position the step left behind (environment.py:332-347)
@@ -293,16 +304,31 @@ def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_
         res["reward_abs"] = max(res["reward_abs"], abs(float(reward) - float(got_w["reward"][i])))
         grel = float((g - got_w["grad"][i]).norm() / g.norm().clamp(min=1e-6))
         res["grad_rel"] = max(res["grad_rel"], grel)
-        if grel >= TOL:  # fp32 cancellation noise or a real error?  the f64 oracle arbitrates
+        if grel >= TOL:  # fp32 cancellation noise or a real error?  the f64 oracle arbitrates (module docstring)
             g64 = _oracle_grad64(case, i, img, radius, w)
+            mass = gradient_mass(got_w, i, w)
             e_gpu = float((got_w["grad"][i].double() - g64).norm())
             e_orc = float((g.double() - g64).norm())
-            ok = e_gpu <= max(TOL * float(g64.norm()), 3.0 * e_orc)
-            res["grad_arbiter"].append(dict(env=i, rel32=grel, g64=float(g64.norm()), e_gpu=e_gpu, e_orc32=e_orc, ok=ok))
+            bound = TOL * float(g64.norm()) + GRAD_NOISE_ULPS * 2.0 ** -24 * mass
+            ok = e_gpu <= bound
+            res["grad_arbiter"].append(dict(env=i, rel32=grel, g64=float(g64.norm()), mass=mass, e_gpu=e_gpu, e_orc32=e_orc,
+                                            bound=bound, ok=ok))
             if not ok:
                 res["grad_excess"] = max(res["grad_excess"], e_gpu / max(float(g64.norm()), 1e-12))
         assert finished == bool(got_w["done"][i]), (i, lo, float(got_w["loss"][i]))
     return res
+
+
+def gradient_mass(got, i, w):
+    """L1 mass of the per-pixel terms of d reward / d action of env i (norm over the two action components):
+    sum_px w |2 I dI/d alpha_o| |d alpha_o / d(el, az)| through |J| / objectMass (occ_combine.hpp, occ_finish_kernel)."""
+    og = got["obj_grad"][i]
+    a = got["alphas"][i]
+    I = a[0] * a[1] + a[1] * a[2] + a[0] * a[2]
+    gsum = torch.stack([a[1] + a[2], a[0] + a[2], a[0] + a[1]])
+    dal = torch.where((a > 0)[..., None], og, torch.zeros(()))  # the planes are only defined where the object is
+    mass = ((2 * I * w)[None, :, :, None] * gsum[..., None] * dal).abs().sum((0, 1, 2))  # (2,): el, az
+    return float((got["jac"][i].abs().t() @ mass).norm() / float(got["object_mass"][i]))
 
 
 def _oracle_grad64(case, i, img, radius, w):
