@@ -67,6 +67,11 @@ extern "C" {
 #define OCC_CAM_LOOKAT 1   /* environment.py:308: look_at_view_transform(radius, el, az)        */
 #define OCC_CAM_POSITION 2 /* environment.py:334-335: look_at_rotation(camera_position)         */
 
+/* OccScene.shader */
+#define OCC_SHADER_FLAT 0
+#define OCC_SHADER_HARD_PHONG 1
+#define OCC_SHADER_SOFT_PHONG 2
+
 /* occ_render flags */
 #define OCC_RENDER_SOFT 1  /* three soft silhouettes + occlusion image + loss */
 #define OCC_RENDER_HARD 2  /* flat-shaded RGB-D observation of the joined scene */
@@ -96,6 +101,12 @@ typedef struct OccScene {
      * its gradient likewise (NULL = 1 everywhere = environment.py:381).  Images are not affected.  Used to score a
      * region of interest, and by the parity tests to leave out pixels classified as exact ties. */
     const float* pix_weight;
+    /* Shader of the RGB-D observation (environment.py:281-283): OCC_SHADER_FLAT = HardFlatShader (what the reference
+     * runs), OCC_SHADER_HARD_PHONG / OCC_SHADER_SOFT_PHONG = the two alternatives it keeps commented out (per-pixel
+     * Phong shading with interpolated vertex normals; soft = softmax_rgb_blend with default BlendParams).  The Phong
+     * shaders need pool_vnormals (sumV,3): [P3D] Meshes.verts_normals_packed() of every pool mesh. */
+    int32_t shader;
+    const float* pool_vnormals;
 } OccScene;
 
 /* Caller-allocated scratch; sizes from occ_workspace_query(). */

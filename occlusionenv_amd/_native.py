@@ -22,6 +22,7 @@ MAX_K = 128
 CAM_STEP, CAM_LOOKAT, CAM_POSITION = 0, 1, 2
 RENDER_SOFT, RENDER_HARD, RENDER_GRAD = 1, 2, 4
 STATUS_LIST_OVERFLOW, STATUS_REC_OVERFLOW = 1, 2
+SHADER_FLAT, SHADER_HARD_PHONG, SHADER_SOFT_PHONG = 0, 1, 2
 
 # camera buffer slots
 C_R, C_T, C_C, C_J, C_EL, C_AZ = 0, 9, 12, 39, 43, 44
@@ -44,6 +45,8 @@ class OccScene(C.Structure):
         ("atlas_res", C.c_int32),
         ("skip", C.c_void_p),
         ("pix_weight", C.c_void_p),
+        ("shader", C.c_int32),
+        ("pool_vnormals", C.c_void_p),
     ]
 
 

@@ -119,29 +119,31 @@ __global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bp
             float q0 = w0 / den, q1 = w1 / den, q2 = w2 / den;
             float tr = q0 + q1 + q2, tg = tr, tb = tr;
             const int64_t aoff = P.sc.pool_atlas ? P.sc.mesh_atlas_off[mesh] : -1;
-            if (aoff >= 0) {
-                if (__float_as_int(r[R_FLAGS]) & FLAG_CLIPPED) {
-                    // [P3D] convert_clipped_rasterization_to_original_faces: barycentrics w.r.t. the ORIGINAL face.
-                    // Perspective-correct barycentrics are the 3-D ones: beta_i ~ d . (V_j x V_k) with d the pixel ray
-                    // and V the face's view-space vertices (valid for vertices behind the clip plane too).
-                    float V[3][3];
+            const int shader = P.sc.pool_vnormals ? P.sc.shader : OCC_SHADER_FLAT;
+            if ((aoff >= 0 || shader != OCC_SHADER_FLAT) && (__float_as_int(r[R_FLAGS]) & FLAG_CLIPPED)) {
+                // [P3D] convert_clipped_rasterization_to_original_faces: barycentrics w.r.t. the ORIGINAL face.
+                // Perspective-correct barycentrics are the 3-D ones: beta_i ~ d . (V_j x V_k) with d the pixel ray
+                // and V the face's view-space vertices (valid for vertices behind the clip plane too).
+                float V[3][3];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const int vi = P.sc.pool_faces[(size_t)(fo + fid) * 3 + k];
-                        const float* pv = P.sc.pool_verts + (size_t)(vo + vi) * 3;
-                        const float wx_ = pv[0] + ox, wy_ = pv[1] + oy, wz_ = pv[2] + oz;
+                for (int k = 0; k < 3; ++k) {
+                    const int vi = P.sc.pool_faces[(size_t)(fo + fid) * 3 + k];
+                    const float* pv = P.sc.pool_verts + (size_t)(vo + vi) * 3;
+                    const float wx_ = pv[0] + ox, wy_ = pv[1] + oy, wz_ = pv[2] + oz;
 #pragma unroll
-                        for (int j = 0; j < 3; ++j)
-                            V[k][j] = wx_ * cm[C_R + j] + wy_ * cm[C_R + 3 + j] + wz_ * cm[C_R + 6 + j] + cm[C_T + j];
-                    }
-                    const float dx = xf / kProjScale, dy = yf / kProjScale, dz = 1.0f;
-                    auto tri = [&](const float* a, const float* b) {
-                        return dx * (a[1] * b[2] - a[2] * b[1]) + dy * (a[2] * b[0] - a[0] * b[2]) + dz * (a[0] * b[1] - a[1] * b[0]);
-                    };
-                    const float e0 = tri(V[1], V[2]), e1 = tri(V[2], V[0]), e2 = tri(V[0], V[1]);
-                    const float es = e0 + e1 + e2;
-                    q0 = e0 / es; q1 = e1 / es; q2 = e2 / es;
+                    for (int j = 0; j < 3; ++j)
+                        V[k][j] = wx_ * cm[C_R + j] + wy_ * cm[C_R + 3 + j] + wz_ * cm[C_R + 6 + j] + cm[C_T + j];
                 }
+                const float dx = xf / kProjScale, dy = yf / kProjScale, dz = 1.0f;
+                auto tri = [&](const float* a, const float* b) {
+                    return dx * (a[1] * b[2] - a[2] * b[1]) + dy * (a[2] * b[0] - a[0] * b[2]) + dz * (a[0] * b[1] - a[1] * b[0]);
+                };
+                const float e0 = tri(V[1], V[2]), e1 = tri(V[2], V[0]), e2 = tri(V[0], V[1]);
+                const float es = e0 + e1 + e2;
+                q0 = e0 / es; q1 = e1 / es; q2 = e2 / es;
+                tr = tg = tb = q0 + q1 + q2;
+            }
+            if (aoff >= 0) {
                 // [P3D] TexturesAtlas.sample_textures: (w0, w1) -> texel of the R x R grid, upper triangle mirrored
                 const int Rr = P.sc.atlas_res;
                 int wx = min((int)(q0 * (float)Rr), Rr - 1), wy = min((int)(q1 * (float)Rr), Rr - 1);
@@ -150,9 +152,58 @@ __global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bp
                 const float* tx = P.sc.pool_atlas + aoff + (((size_t)fid * Rr + wy) * Rr + wx) * 3;
                 tr = tx[0]; tg = tx[1]; tb = tx[2];
             }
-            cr = amb_diff * tr + spec;
-            cg = amb_diff * tg + spec;
-            cb = amb_diff * tb + spec;
+            float ad = amb_diff, sp = spec;
+            if (shader != OCC_SHADER_FLAT) {
+                // [P3D] phong_shading: position and normal of the PIXEL = barycentric interpolation of the face's
+                // vertex positions / vertex normals (Meshes.verts_normals_packed), lighting as for the flat shader
+                float px_ = 0.f, py_ = 0.f, pz_ = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+                const float qk[3] = {q0, q1, q2};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int vi = P.sc.pool_faces[(size_t)(fo + fid) * 3 + k];
+                    const float* pv = P.sc.pool_verts + (size_t)(vo + vi) * 3;
+                    const float* pn = P.sc.pool_vnormals + (size_t)(vo + vi) * 3;
+                    px_ += qk[k] * (pv[0] + ox); py_ += qk[k] * (pv[1] + oy); pz_ += qk[k] * (pv[2] + oz);
+                    nx += qk[k] * pn[0]; ny += qk[k] * pn[1]; nz += qk[k] * pn[2];
+                }
+                auto inv_len = [](float x, float y, float z) { return frcp(fmaxf(__builtin_amdgcn_sqrtf(x * x + y * y + z * z), kShadeEps)); };
+                const float in_ = inv_len(nx, ny, nz);
+                nx *= in_; ny *= in_; nz *= in_;
+                float lx = kLightX - px_, ly = kLightY - py_, lz = kLightZ - pz_;
+                const float il = inv_len(lx, ly, lz);
+                lx *= il; ly *= il; lz *= il;
+                const float cosang = nx * lx + ny * ly + nz * lz;
+                float vx = cm[C_C] - px_, vy = cm[C_C + 1] - py_, vz = cm[C_C + 2] - pz_;
+                const float iv = inv_len(vx, vy, vz);
+                vx *= iv; vy *= iv; vz *= iv;
+                const float rx = -lx + 2.f * (cosang * nx), ry = -ly + 2.f * (cosang * ny), rz = -lz + 2.f * (cosang * nz);
+                float sa = fmaxf(vx * rx + vy * ry + vz * rz, 0.f) * (cosang > 0.f ? 1.f : 0.f);
+                sa *= sa; sa *= sa; sa *= sa; sa *= sa; sa *= sa; sa *= sa;  // ^64
+                ad = kAmbient + kDiffuse * fmaxf(cosang, 0.f);
+                sp = kSpecular * sa;
+            }
+            cr = ad * tr + sp;
+            cg = ad * tg + sp;
+            cb = ad * tb + sp;
+            if (shader == OCC_SHADER_SOFT_PHONG) {
+                // [P3D] softmax_rgb_blend with K = 1, BlendParams() defaults (sigma = gamma = 1e-4, white background),
+                // znear 1, zfar 100: weight = sigmoid(|d| / sigma) of the one face against delta = exp((eps - z_inv)/gamma)
+                auto seg = [&](float ax, float ay, float bx, float by) {
+                    const float ex = bx - ax, ey = by - ay, l2 = ex * ex + ey * ey;
+                    if (l2 <= kEpsilon) return (xf - bx) * (xf - bx) + (yf - by) * (yf - by);
+                    const float t = clamp01((ex * (xf - ax) + ey * (yf - ay)) / l2);
+                    const float qx = ax + t * ex - xf, qy = ay + t * ey - yf;
+                    return qx * qx + qy * qy;
+                };
+                const float dist = fmin3(seg(x0, y0, x1, y1), seg(x0, y0, x2, y2), seg(x1, y1, x2, y2));
+                const float prob = 1.0f / (1.0f + __expf(-dist * kInvSigma));
+                const float z_inv = fmaxf((100.0f - hz) / 99.0f, 1e-10f);
+                const float delta = fmaxf(__expf((1e-10f - z_inv) * kInvSigma), 1e-10f);
+                const float id = 1.0f / (prob + delta);
+                cr = (prob * cr + delta) * id;
+                cg = (prob * cg + delta) * id;
+                cb = (prob * cb + delta) * id;
+            }
             depth = hz;
         }
         float* __restrict__ ob = P.out.obs + (size_t)env * 4 * S * S + gp;

@@ -128,7 +128,8 @@ extern "C" int occ_device_cu_count(void) {
 static bool scene_ok(const OccScene* s) {
     return s && s->pool_verts && s->pool_faces && s->mesh_vert_off && s->mesh_face_off && s->scene_mesh &&
            s->scene_offset && s->n_env > 0 && s->img >= OCC_TILE && s->img % OCC_TILE == 0 && s->img <= 2048 &&
-           s->rec_cap > 0;
+           s->rec_cap > 0 && s->shader >= OCC_SHADER_FLAT && s->shader <= OCC_SHADER_SOFT_PHONG &&
+           (s->shader == OCC_SHADER_FLAT || s->pool_vnormals);
 }
 
 extern "C" int occ_workspace_query(const OccScene* scene, int n_slots, OccWorkspaceSizes* out) {

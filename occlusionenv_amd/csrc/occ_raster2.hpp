@@ -27,7 +27,8 @@
 //     contiguously; every entry bumps the LDS histogram of ITS pixel; the pixel's owner lane (lane = pixel) scans its
 //     32 buckets and narrows its window; sweeps keep eight 512-byte loads in flight (a sweep with one dependent
 //     load per iteration is pure L2 latency).  Afterwards one more sweep re-accumulates the kept entries of the
-//     overflowing pixels (log-domain product via LDS atomics: <= K entries per such pixel).  When the log fills up (thousands of candidates per pixel: far cameras, dense meshes) the
+//     overflowing pixels (log-domain product via LDS atomics: <= K entries per such pixel; replacing those atomics by
+//     rank-by-pixel plain read-modify-write - six ballots per row - was measured and is slower).  When the log fills up (thousands of candidates per pixel: far cameras, dense meshes) the
 //     same machinery keeps each overflowing pixel's K nearest and compacts the log in place; pruning bounds as before.
 //
 // Semantics are those of occ_raster.hpp: same eval_face, same candidate rule, same K-nearest-by-z
@@ -198,20 +199,6 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             return max(max(s_akm[myslot], s_akm[kAccStride + myslot]), max(s_akm[2 * kAccStride + myslot], s_akm[3 * kAccStride + myslot]));
         };
 
-        // Rank of this lane among the (valid) lanes of the wave that hold the same 6-bit pixel tag: lanes of equal rank
-        // have distinct pixels, so a loop over ranks can update per-pixel LDS state with plain loads and stores.
-        // (LDS atomics that collide on an address cost 20 - 60 cycles per lane here; six ballots cost ~40 instructions.)
-        auto same_tag_rank = [&](const uint32_t tag, const bool valid) __attribute__((always_inline)) -> int {
-            unsigned long long peers = __ballot(valid);
-#pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                const bool bit = (tag >> b) & 1u;
-                const unsigned long long mb = __ballot(valid && bit);
-                peers &= bit ? mb : ~mb;
-            }
-            return valid ? (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u)) : 0x7FFFFFFF;
-        };
-
         // ---- exact top-K over the log for every pixel holding more than K entries ---------------------------
         // Leaves the sums of those pixels' K nearest in s_acc2 (and s_kmax2 when compacting) and returns whether
         // this lane's pixel was one of them.  COMPACT also rewrites the log so that it holds exactly the entries still
@@ -276,12 +263,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                                     hit = k >= w.x && d < (1u << kSelBits);
                                 }
                             }
-                            if (__ballot(hit)) {
-                                const int rk = same_tag_rank(t, hit);
-                                for (int i = 0; __ballot(hit && rk >= i); ++i) {
-                                    if (hit && rk == i) hist[t * kSelDw + (d >> 1)] += 1u << (16 * (d & 1u));
-                                }
-                            }
+                            if (hit) atomicAdd(&hist[t * kSelDw + (d >> 1)], 1u << (16 * (d & 1u)));
                         }
                     }
                 }
@@ -363,24 +345,17 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 }
 #pragma unroll
                 for (int u = 0; u < kSweepU; ++u) {
-                    const bool rd = (readdm >> u) & 1u;
-                    if (__ballot(rd)) {
-                        // product of the kept (1 - p_k) in the log domain: exp2(sum log2); log2(0) = -inf -> 0
-                        const float lq = __builtin_amdgcn_logf(pv[u].x);
+                    if ((readdm >> u) & 1u) {
                         const uint32_t t = kt[u].y & 63u;
-                        const int rk = same_tag_rank(t, rd);
-                        for (int i = 0; __ballot(rd && rk >= i); ++i) {
-                            if (rd && rk == i) {
-                                float4 a = s_acc2[t];
-                                a.x += lq;
-                                if (GRAD) {
-                                    a.y += pv[u].y;
-                                    a.z += pv[u].z;
-                                }
-                                a.w += 1.0f;
-                                s_acc2[t] = a;
-                                if (compact) s_kmax2[t] = max(s_kmax2[t], kt[u].x);
-                            }
+                        // product of the kept (1 - p_k) in the log domain: exp2(sum log2); log2(0) = -inf -> 0
+                        atomicAdd(&s_acc2[t].x, __builtin_amdgcn_logf(pv[u].x));
+                        if (GRAD) {
+                            atomicAdd(&s_acc2[t].y, pv[u].y);
+                            atomicAdd(&s_acc2[t].z, pv[u].z);
+                        }
+                        if (compact) {  // count and largest key only matter when the loop goes on
+                            atomicAdd(&s_acc2[t].w, 1.0f);
+                            atomicMax(&s_kmax2[t], kt[u].x);
                         }
                     }
                     if (compact) {

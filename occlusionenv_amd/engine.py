@@ -100,6 +100,9 @@ class OcclusionEngine:
         self._reserve_cam_done = False
         # optional (N,S,S) weight of every pixel's loss term (OccScene.pix_weight); None = 1 (environment.py:381)
         self.pixel_weight: Optional[torch.Tensor] = None
+        # shader of the RGB-D observation: nat.SHADER_FLAT (HardFlatShader, environment.py:283) or one of the two
+        # alternatives the reference keeps commented out (environment.py:281-282)
+        self.shader = nat.SHADER_FLAT
         if self.R:
             # device-side auto-reset state (include/occlusionenv_amd.h: occ_auto_reset)
             i32 = dict(dtype=torch.int32, device=d)
@@ -144,6 +147,9 @@ class OcclusionEngine:
             sc.pool_atlas, sc.mesh_atlas_off, sc.atlas_res = atlas.data_ptr(), aoff.data_ptr(), self.pool.atlas_res
         if skip is not None:
             sc.skip = skip.data_ptr()
+        if self.shader != nat.SHADER_FLAT:
+            sc.shader = int(self.shader)
+            sc.pool_vnormals = self.pool.vertex_normals_tensor().data_ptr()
         if pix_weight is not None:
             if pix_weight.shape != (n, self.S, self.S) or pix_weight.dtype != torch.float32 or not pix_weight.is_contiguous():
                 raise ValueError(f"pixel weights must be a contiguous float32 ({n}, {self.S}, {self.S}) tensor")

@@ -210,6 +210,22 @@ class OcclusionEnv:
         if torch.cuda.is_available():
             torch.cuda.manual_seed(seed)
 
+    # ``shader`` picks the shader of phong_renderer, which the reference does by (un)commenting a line of
+    # createRenderers (environment.py:281-283): "flat" = HardFlatShader (the one it runs), "hard_phong" =
+    # HardPhongShader, "soft_phong" = SoftPhongShader.  Engine-wide: the envs of one VecEnv share it.
+    _SHADERS = {"flat": nat.SHADER_FLAT, "hard_phong": nat.SHADER_HARD_PHONG, "soft_phong": nat.SHADER_SOFT_PHONG}
+
+    @property
+    def shader(self) -> str:
+        code = self._eng().shader
+        return next(k for k, v in self._SHADERS.items() if v == code)
+
+    @shader.setter
+    def shader(self, name: str) -> None:
+        if name not in self._SHADERS:
+            raise ValueError(f"shader must be one of {sorted(self._SHADERS)}")
+        self._eng().shader = self._SHADERS[name]
+
     def createRenderers(self, mesh_size):
         """Renderer constants only (environment.py:234-284): sigma, blur radius, K=100/1, lights and camera
         defaults are compiled into the kernels (csrc/occ_constants.h); ``max_faces_per_bin`` has no

@@ -296,6 +296,25 @@ class MeshPool:
             self._d_atlas.append(torch.cat(chunks))
         self._flushed = m1
 
+    def vertex_normals_tensor(self) -> torch.Tensor:
+        """(sumV,3) f32 on the device: [P3D] ``Meshes.verts_normals_packed()`` of every pool mesh (each face adds its
+        area-weighted normal to its three corners, sums normalised with eps 1e-6) - what HardPhongShader /
+        SoftPhongShader interpolate (environment.py:281-282).  Built on first use and when the pool has grown."""
+        self._flush()
+        if getattr(self, "_vn_version", -1) != self._flushed:
+            out = []
+            for v, f in zip(self._verts[: self._flushed], self._faces[: self._flushed]):
+                fl = f.long()
+                vf = v[fl]
+                n = torch.zeros_like(v)
+                n.index_add_(0, fl[:, 1], torch.cross(vf[:, 2] - vf[:, 1], vf[:, 0] - vf[:, 1], dim=1))
+                n.index_add_(0, fl[:, 2], torch.cross(vf[:, 0] - vf[:, 2], vf[:, 1] - vf[:, 2], dim=1))
+                n.index_add_(0, fl[:, 0], torch.cross(vf[:, 1] - vf[:, 0], vf[:, 2] - vf[:, 0], dim=1))
+                out.append(torch.nn.functional.normalize(n, eps=1e-6, dim=1))
+            self._d_vnorm = torch.cat(out).to(self.device).contiguous()
+            self._vn_version = self._flushed
+        return self._d_vnorm
+
     def atlas_tensors(self):
         """(packed atlas floats, per-mesh float offsets int64 with -1 = untextured) on the device, or (None, None)."""
         self._flush()

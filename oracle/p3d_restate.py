@@ -351,6 +351,72 @@ def hard_flat_rgbd(verts_world, faces, R, T, S, verts_rgb=None, atlas=None):
     return torch.cat([pix, a], dim=-1), zbuf
 
 
+def vertex_normals(verts, faces):
+    """[P3D] Meshes.verts_normals_packed(): every face adds its (area-weighted) normal to its three corners, the sums
+    are normalised with eps 1e-6."""
+    vf = verts[faces]
+    n = torch.zeros_like(verts)
+    n = n.index_add(0, faces[:, 1], torch.cross(vf[:, 2] - vf[:, 1], vf[:, 0] - vf[:, 1], dim=1))
+    n = n.index_add(0, faces[:, 2], torch.cross(vf[:, 0] - vf[:, 2], vf[:, 1] - vf[:, 2], dim=1))
+    n = n.index_add(0, faces[:, 0], torch.cross(vf[:, 1] - vf[:, 0], vf[:, 2] - vf[:, 0], dim=1))
+    return F.normalize(n, eps=1e-6, dim=1)
+
+
+def phong_rgbd(verts_world, faces, R, T, S, soft=False, atlas=None, vnormals=None):
+    """phong_renderer with the two shaders the reference keeps commented out next to HardFlatShader
+    (environment.py:281-282): HardPhongShader (soft=False) / SoftPhongShader (soft=True), both with the renderer's
+    K = 1, blur 0 rasterisation (environment.py:267-273) and default BlendParams (sigma = gamma = 1e-4, white
+    background), znear 1 / zfar 100 from FoVPerspectiveCameras.  [P3D] phong_shading: pixel position and normal are
+    barycentric interpolations of the face's vertex positions / vertex normals; lighting as in A.7;
+    softmax_rgb_blend as published.  Returns (image (S,S,4), zbuf (S,S,1))."""
+    dt = verts_world.dtype
+    ndc = world_to_ndc(verts_world, R, T)
+    p2f, zbuf, bary, dists = rasterize_meshes(ndc[faces], S, 0.0, K_HARD)
+    vn = vertex_normals(verts_world, faces) if vnormals is None else vnormals
+    mask = p2f == -1
+    idx = p2f.clamp(min=0)
+    fverts, fnorm = verts_world[faces], vn[faces]
+    pcoords = (bary[..., None] * fverts[idx]).sum(dim=-2)
+    pnormals = (bary[..., None] * fnorm[idx]).sum(dim=-2)
+    pcoords = torch.where(mask[..., None], torch.zeros_like(pcoords), pcoords)
+    pnormals = torch.where(mask[..., None], torch.zeros_like(pnormals), pnormals)
+    texels = torch.where(mask[..., None], torch.zeros_like(pcoords), bary.sum(-1, keepdim=True).expand_as(pcoords))  # white verts
+    if atlas is not None:
+        texels = sample_atlas(atlas.to(dt), p2f, bary)
+    L = torch.tensor(LIGHT_LOCATION, dtype=dt)
+    M = torch.eye(4, dtype=dt)
+    M[:3, :3] = R
+    M[3, :3] = T
+    C = torch.linalg.inv(M)[3, :3]
+    nrm = F.normalize(pnormals, p=2, dim=-1, eps=1e-6)
+    direction = F.normalize(L - pcoords, p=2, dim=-1, eps=1e-6)
+    cos_angle = torch.sum(nrm * direction, dim=-1)
+    diffuse = DIFFUSE * F.relu(cos_angle)[..., None]
+    smask = (cos_angle > 0).to(dt)
+    view_dir = F.normalize(C - pcoords, p=2, dim=-1, eps=1e-6)
+    reflect = -direction + 2 * (cos_angle[..., None] * nrm)
+    alpha = F.relu(torch.sum(view_dir * reflect, dim=-1)) * smask
+    specular = SPECULAR * torch.pow(alpha, SHININESS)[..., None]
+    colors = (AMBIENT + diffuse) * texels + specular  # (S,S,1,3)
+    if not soft:  # hard_rgb_blend
+        is_bg = p2f[..., 0] < 0
+        pix = torch.where(is_bg[..., None], torch.ones_like(colors[..., 0, :]), colors[..., 0, :])
+        return torch.cat([pix, (~is_bg).to(dt)[..., None]], dim=-1), zbuf
+    # softmax_rgb_blend(colors, fragments, BlendParams(), znear=1, zfar=100)
+    sigma, gamma, znear, zfar, eps = SIGMA, 1e-4, 1.0, 100.0, 1e-10
+    m = (p2f >= 0).to(dt)
+    prob = torch.sigmoid(-dists / sigma) * m
+    alpha_px = torch.prod(1.0 - prob, dim=-1)
+    z_inv = (zfar - zbuf) / (zfar - znear) * m
+    z_inv_max = torch.max(z_inv, dim=-1).values[..., None].clamp(min=eps)
+    weights_num = prob * torch.exp((z_inv - z_inv_max) / gamma)
+    delta = torch.exp((eps - z_inv_max) / gamma).clamp(min=eps)
+    denom = weights_num.sum(dim=-1)[..., None] + delta
+    wcol = (weights_num[..., None] * colors).sum(dim=-2)
+    rgb = (wcol + delta * torch.ones(3, dtype=dt)) / denom
+    return torch.cat([rgb, (1.0 - alpha_px)[..., None]], dim=-1), zbuf
+
+
 # ---- environment (environment.py:286-402) ---------------------------------------------------
 class OracleEnv:
     """Restatement of OcclusionEnv.reset/step/render for ONE env on the CPU.
@@ -375,14 +441,22 @@ class OracleEnv:
         # optional (S,S) weight of every pixel's term of the loss (tests: 0 on pixels classified as exact ties, so
         # that loss / reward / gradient are compared over the remaining pixels; the product's OccScene.pix_weight)
         self.pixel_weight = None
+        # shader of the observation renderer: "flat" = HardFlatShader (environment.py:283, what the reference runs);
+        # "hard_phong" / "soft_phong" = the alternatives it keeps commented out (environment.py:281-282)
+        self.shader = "flat"
 
     def _loss(self):
         sq = self.image[..., 3] ** 2
         return torch.sum(sq if self.pixel_weight is None else sq * self.pixel_weight.to(sq.dtype))
 
+    def _observe(self, R, T):
+        if self.shader == "flat":
+            return hard_flat_rgbd(self.scene[0], self.scene[1], R[0], T[0], self.S, atlas=self.atlas)
+        return phong_rgbd(self.scene[0], self.scene[1], R[0], T[0], self.S, soft=(self.shader == "soft_phong"), atlas=self.atlas)
+
     def _render_all(self, R, T):
         S = self.S
-        obs_img, depth = hard_flat_rgbd(self.scene[0], self.scene[1], R[0], T[0], S, atlas=self.atlas)
+        obs_img, depth = self._observe(R, T)
         observation = obs_img[None].permute(0, 3, 1, 2).clone()
         observation[:, 3] = depth[None].permute(0, 3, 1, 2)[:, 0]
         imgs = [soft_silhouette(v, f, R[0], T[0], S)[None] for v, f in self.objs]
@@ -429,5 +503,5 @@ class OracleEnv:
     def render(self):
         R = look_at_rotation(self.camera_position[None, :])
         T = translation_from(R, self.camera_position[None, :])
-        img, depth = hard_flat_rgbd(self.scene[0], self.scene[1], R[0], T[0], self.S, atlas=self.atlas)
+        img, depth = self._observe(R, T)
         return img[None], depth[None]

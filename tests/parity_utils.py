@@ -77,7 +77,7 @@ def make_case(n_env, seed, mesh="teapot", az_range=0.6, pool=None, device="cuda"
     return dict(pool=pool, mesh_ids=mesh_ids, offsets=offsets, az=az, actions=actions)
 
 
-def oracle_env(case, i, img):
+def oracle_env(case, i, img, shader="flat"):
     from oracle import p3d_restate as O
 
     objs, atl = [], []
@@ -86,14 +86,18 @@ def oracle_env(case, i, img):
         v, f = case["pool"].get(mid)
         objs.append((v + case["offsets"][i, o], f))
         atl.append(case["pool"].get_atlas(mid))
-    return O.OracleEnv(objs, img, atlases=atl if all(a is not None for a in atl) else None)
+    env = O.OracleEnv(objs, img, atlases=atl if all(a is not None for a in atl) else None)
+    env.shader = shader
+    return env
 
 
-def run_engine(case, img, n_env=None, faces_per_pixel=100, radius=4.0, pixel_weight=None, render_too=False):
+def run_engine(case, img, n_env=None, faces_per_pixel=100, radius=4.0, pixel_weight=None, render_too=False, shader="flat"):
+    from occlusionenv_amd import _native as nat
     from occlusionenv_amd.engine import OcclusionEngine
 
     n = n_env or case["mesh_ids"].shape[0]
     eng = OcclusionEngine(case["pool"], n, img, faces_per_pixel=faces_per_pixel)
+    eng.shader = {"flat": nat.SHADER_FLAT, "hard_phong": nat.SHADER_HARD_PHONG, "soft_phong": nat.SHADER_SOFT_PHONG}[shader]
     eng.set_scene(list(range(n)), case["mesh_ids"][:n], case["offsets"][:n])
     if pixel_weight is not None:
         eng.pixel_weight = pixel_weight.to(eng.device, torch.float32).contiguous()
@@ -103,7 +107,6 @@ def run_engine(case, img, n_env=None, faces_per_pixel=100, radius=4.0, pixel_wei
     obs, reward, done, fs, loss = eng.step(a)
     reward.sum().backward()
     eng.check_status()
-    from occlusionenv_amd import _native as nat
     S = img
     # what the gradient is made of (gradient_mass): per-object d alpha / d(el, az) planes, action Jacobian, objectMass
     og = eng._ws_tensors["obj_grad"].view(torch.float32)[: n * 3 * S * S * 2].view(n, 3, S, S, 2).cpu().clone()
@@ -236,7 +239,7 @@ def _classify(env, got_alphas, or_alphas, got_obs, or_obs, S, K, textured):
 
 
 def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_envs=None, radius=4.0, mutate=None,
-                    faces_per_pixel=100, check_render=False):
+                    faces_per_pixel=100, check_render=False, shader="flat"):
     """One seeded batch through the HIP engine and the oracle.  Returns the worst differences over the checked envs
     (all pixels that are not explained exact ties; loss / reward / gradient with the ties weighted out on both
     sides) plus ``unexplained`` (must be empty) and ``tie_pixels`` (count, bounded by the caller)."""
@@ -245,13 +248,13 @@ def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_
     case = make_case(n_env, seed, mesh, az_range)
     if mutate is not None:
         mutate(case)  # e.g. push an object out of view
-    got = run_engine(case, img, radius=radius, faces_per_pixel=faces_per_pixel, render_too=check_render)
+    got = run_engine(case, img, radius=radius, faces_per_pixel=faces_per_pixel, render_too=check_render, shader=shader)
     S, K = img, faces_per_pixel
     envs = list(check_envs if check_envs is not None else range(n_env))
     textured = mesh == "textured"
     orc, weights, unexplained, n_ties = {}, torch.ones(n_env, S, S), [], 0
     for i in envs:
-        env = oracle_env(case, i, img)
+        env = oracle_env(case, i, img, shader)
         obs0 = env.reset(radius=radius, azimuth=float(case["az"][i]))
         al0 = torch.stack([im[0, ..., 3] for im in env.alphas]).detach()
         img0 = env.image.detach()
@@ -271,7 +274,7 @@ def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_
         orc[i] = dict(env=env, obs0=obs0[0].detach(), al0=al0, img0=img0, a=a, obs=obs[0].detach(), al=al, ties=ties,
                       t0=t0, t1=t1, render=rnd)
     if n_ties:  # leave the tie pixels out of the loss on the GPU side too
-        got_w = run_engine(case, img, radius=radius, faces_per_pixel=faces_per_pixel, pixel_weight=weights)
+        got_w = run_engine(case, img, radius=radius, faces_per_pixel=faces_per_pixel, pixel_weight=weights, shader=shader)
     else:
         got_w = got
     res = dict(obs_maxabs=0.0, obs0_maxabs=0.0, alpha_maxabs=0.0, alpha0_maxabs=0.0, fs_maxabs=0.0, loss_rel=0.0,

@@ -471,3 +471,46 @@ print("FAULT", list(buf), "finite", bool(torch.isfinite(loss).all() and torch.is
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("FAULT")][-1]
     assert "FAULT [0, 0, 0, 0, 0, 0, 0, 0] finite True" in line, line
+
+
+def test_record_arrays_are_sized_after_the_pre_launch_hook():
+    """Advisor finding (round 1): a reset that runs inside step()'s pre_launch hook (SimpleVecEnv's synchronous
+    fallback when the reserve is dry) can hand envs LARGER models that are already in the pool - pool.version does not
+    move - so the variable-layout record arrays must be sized AFTER the hook, not before.  Here the hook switches every
+    env from 1 280-face to 20 480-face meshes: without the fix the tail objects get an empty record span, raise
+    OCC_STATUS_REC_OVERFLOW and render nothing."""
+    from occlusionenv_amd.engine import OcclusionEngine
+    from occlusionenv_amd.meshes import MeshPool, SyntheticShapeNet
+
+    ds = SyntheticShapeNet(n_models=12, seed=77, mixed=True)
+    pool = MeshPool("cuda")
+    ids = [pool.add(*ds.models[i], key=("m", i)) for i in range(len(ds.models))]
+    faces = [pool.num_faces(i) for i in ids]
+    small, big = faces.index(min(faces)), faces.index(max(faces))
+    assert faces[big] >= 8 * faces[small]
+    N, S = 6, 64
+    eng = OcclusionEngine(pool, N, S, reserve=2)
+    off = torch.zeros(N, 3, 3)
+    off[:, 1, 0], off[:, 1, 2] = 0.4, 1.0
+    off[:, 2, 0], off[:, 2, 2] = -0.4, 2.0
+    eng.set_scene(list(range(N)), torch.full((N, 3), small), off)
+    eng.reset_render(None, 4.0, 0.0, 0.0)
+    small_total = eng._rec_total
+    version = pool.version
+
+    def hook():  # what _drain()'s fallback reset does: new scenes for (here: all) envs, same pool
+        eng.set_scene(list(range(N)), torch.full((N, 3), big), off)
+
+    a = torch.randn(N, 2, device="cuda", requires_grad=True)
+    obs, reward, done, fs, loss, out = eng.step(a, with_reserve=True, pre_launch=hook)
+    reward.sum().backward()
+    eng.check_status()  # raises on OCC_STATUS_REC_OVERFLOW
+    assert pool.version == version and eng._rec_total > small_total
+    assert torch.isfinite(obs).all() and torch.isfinite(a.grad).all()
+    # the big meshes really were rendered: compare with a fresh engine that had them from the start
+    eng2 = OcclusionEngine(pool, N, S)
+    eng2.set_scene(list(range(N)), torch.full((N, 3), big), off)
+    eng2.elevation.copy_(eng.elevation - 0.0)
+    assert float(eng.alphas.sum()) > 0
+    obs2 = eng2.render_hard()  # camera_position = 0 there: only checks the pool/record path runs at this size
+    assert torch.isfinite(obs2).all()

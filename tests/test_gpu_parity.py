@@ -157,6 +157,16 @@ def test_multi_step_trajectory_matches_oracle():
         a_o = (a_o + lr * ao.grad).detach()
 
 
+@pytest.mark.parametrize("shader", ["hard_phong", "soft_phong"])
+def test_phong_shader_alternatives(shader):
+    """The two observation shaders the reference keeps commented out beside HardFlatShader (environment.py:281-282):
+    per-pixel Phong shading with interpolated vertex normals, hard blend / softmax blend (K = 1, default BlendParams);
+    white vertices, texture atlases, and a camera inside the scene (barycentrics of z-clipped faces)."""
+    _check(run_parity_case(n_env=2, img=64, seed=51, mesh="teapot", shader=shader, check_render=True))
+    _check(run_parity_case(n_env=2, img=64, seed=52, mesh="textured", shader=shader))
+    _check(run_parity_case(n_env=1, img=64, seed=53, mesh="teapot", shader=shader, radius=1.2, az_range=0.3))
+
+
 def test_camera_degenerate_look_at_branch():
     """[P3D] look_at_rotation's `C parallel to up` branch (x = normalize(cross(y, z)) when x ~ 0,
     occ_camera.hpp) through OCC_CAM_POSITION, against the oracle; regular and near-degenerate positions alongside."""
