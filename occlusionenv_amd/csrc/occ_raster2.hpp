@@ -25,8 +25,8 @@
 //     the tile collected more than K candidates.
 //   * COOPERATIVE EXACT TOP-K.  Radix select (5 bits per level) over the log with all 64 lanes sweeping it
 //     contiguously; every entry bumps the LDS histogram of ITS pixel; the pixel's owner lane (lane = pixel) scans its
-//     32 buckets and narrows its window; sweeps keep eight 512-byte loads in flight (a sweep with one dependent
-//     load per iteration is pure L2 latency).  Afterwards one more sweep re-accumulates the kept entries of the
+//     32 buckets and narrows its window; sweeps keep two groups of four 512-byte loads in flight (a sweep with one
+//     dependent load per iteration is pure memory latency).  Afterwards one more sweep re-accumulates the kept entries of the
 //     overflowing pixels (log-domain product via LDS atomics: <= K entries per such pixel; replacing those atomics by
 //     rank-by-pixel plain read-modify-write - six ballots per row - was measured and is slower).  When the log fills up (thousands of candidates per pixel: far cameras, dense meshes) the
 //     same machinery keeps each overflowing pixel's K nearest and compacts the log in place; pruning bounds as before.
@@ -46,8 +46,8 @@ constexpr int kStgPad = 33;    // LDS stride (float4) between the parts of the s
 constexpr int kPairCap = 2048; // pairs per batch at most (kStg2 faces x 64 pixels): one byte each in the pair map
 constexpr int kSelBits = 5;    // radix-select digit: 32 u16 buckets = 16 dwords per pixel (4 KB, aliasing records + descriptors)
 constexpr int kSelDw = (1 << kSelBits) / 2;
-constexpr int kSweepU = 8;     // 64-entry rows of the log per group of the final sweep
-constexpr int kHistU = 8;      // 128-entry double rows in flight in a histogram sweep
+constexpr int kSweepU = 4;     // 64-entry rows of the log per sweep group; two groups are in flight (wider groups /
+                               // 16-byte double rows were measured slower: they push the kernel into spilling)
 constexpr int kListCap = 8;    // boundary-bucket entries per pixel that the owner lane resolves itself
 constexpr int kCopies = 4;     // accumulator copies (staged face & 3)
 constexpr int kAccStride = 73; // float4 slots per copy: pixel slot = 9 * py + px, copy stride = 9 mod 16 -> bank-spread
@@ -239,32 +239,26 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #pragma unroll
                 for (int i = 0; i < kSelDw; i += 4) reinterpret_cast<uint4*>(hist + lane * kSelDw)[i >> 2] = make_uint4(0u, 0u, 0u, 0u);
                 __syncthreads();
-                // histogram sweep: order is irrelevant, so every lane takes PAIRS of entries with 16-byte loads,
-                // kHistU of them in flight (8 KB per wave)
-                for (int e0 = 0; e0 < nlog; e0 += 128 * kHistU) {
-                    uint4 q[kHistU];
+                auto bump = [&](const uint2 (&kt)[kSweepU]) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int u = 0; u < kHistU; ++u) {
-                        const int e = e0 + u * 128 + 2 * lane;
-                        q[u] = e + 1 < nlog ? reinterpret_cast<const uint4*>(lg.kt)[e >> 1]
-                                            : (e < nlog ? make_uint4(lg.kt[e].x, lg.kt[e].y, 0u, 255u) : make_uint4(0u, 255u, 0u, 255u));
-                    }
-#pragma unroll
-                    for (int u = 0; u < kHistU; ++u) {
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const uint32_t k = h ? q[u].z : q[u].x, t = h ? q[u].w : q[u].y;
-                            bool hit = false;
-                            uint32_t d = 0u;
-                            if (t < 64u) {
-                                const uint2 w = s_sel[t];
-                                if (w.y < 32u) {
-                                    d = (k - w.x) >> w.y;
-                                    hit = k >= w.x && d < (1u << kSelBits);
-                                }
+                    for (int u = 0; u < kSweepU; ++u) {
+                        if (kt[u].y < 64u) {
+                            const uint2 w = s_sel[kt[u].y];
+                            if (w.y < 32u) {
+                                const uint32_t d = (kt[u].x - w.x) >> w.y;
+                                if (kt[u].x >= w.x && d < (1u << kSelBits)) atomicAdd(&hist[kt[u].y * kSelDw + (d >> 1)], 1u << (16 * (d & 1u)));
                             }
-                            if (hit) atomicAdd(&hist[t * kSelDw + (d >> 1)], 1u << (16 * (d & 1u)));
                         }
+                    }
+                };
+                {
+                    uint2 ka[kSweepU], kb[kSweepU];
+                    load_group(0, ka);
+                    for (int e0 = 0; e0 < nlog; e0 += 2 * kGroup) {
+                        load_group(e0 + kGroup, kb);
+                        bump(ka);
+                        load_group(e0 + 2 * kGroup, ka);
+                        bump(kb);
                     }
                 }
                 __syncthreads();
@@ -370,11 +364,20 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     }
                 }
             };
-            {
+            if (compact) {  // in-place rewrite: a group's loads must not run ahead of the previous group's stores
                 uint2 ka[kSweepU];
                 for (int e0 = 0; e0 < nlog; e0 += kGroup) {
                     load_group(e0, ka);
                     settle(e0, ka);
+                }
+            } else {
+                uint2 ka[kSweepU], kb[kSweepU];
+                load_group(0, ka);
+                for (int e0 = 0; e0 < nlog; e0 += 2 * kGroup) {
+                    load_group(e0 + kGroup, kb);
+                    settle(e0, ka);
+                    load_group(e0 + 2 * kGroup, ka);
+                    settle(e0 + kGroup, kb);
                 }
             }
             __syncthreads();

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of raster-kernel builds on ONE box, two interleaved rounds:  bash scripts/dbg/ab.sh
+# A/B of raster-kernel builds on ONE box, interleaved rounds:  bash scripts/dbg/ab.sh
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 run() {  # name, env...
   name=$1; shift
@@ -9,9 +9,8 @@ for l in sys.stdin:
     if l.startswith('{'):
         j = json.loads(l); print('$name', 'raster %.3f ms' % j['roofline']['avg_launch_ms'], 'step %.3f ms' % j['ms_per_step'], '%.0f steps/s' % j['value'])"
 }
-for r in 1 2; do
+for r in 1 2 3; do
   run old OCC_RASTER=1
-  run new X=1
-  run pipe2w OCC_HIP_LIB=$PWD/build/dbg2/libocc_pipe2.so OCC_WAVES_PER_CU=8
-  run new_wpc10 OCC_WAVES_PER_CU=10
+  run newA X=1
+  run newC OCC_HIP_LIB=$PWD/build/dbg2/libocc_vc.so
 done

@@ -11,11 +11,10 @@ ARGS="--steps 6 --warmup 2 --no-cpu-baseline --pool-models 64 $*"
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS" \
            "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE" \
-           "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_WAVES SQ_INST_CYCLES_VMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_ATOMIC_RETURN SQ_LDS_UNALIGNED_STALL"; do
+           "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
   (cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/p$i" -- python "$ROOTD/bench.py" $ARGS > "$OUT/p$i.log" 2>&1)
 done
-(cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python "$ROOTD/bench.py" $ARGS > "$OUT/trace.log" 2>&1)
 python - "$OUT" <<'PY'
 import collections, csv, glob, os, sys
 out = sys.argv[1]
@@ -26,7 +25,4 @@ for f in sorted(glob.glob(os.path.join(out, "p*", "*", "*counter_collection.csv"
             agg[r["Kernel_Name"][:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         print(k, {c: "%.4g" % (sum(x) / len(x)) for c, x in v.items()})
-for f in glob.glob(os.path.join(out, "trace", "*", "*kernel_stats.csv")):
-    for r in list(csv.DictReader(open(f)))[:8]:
-        print(r["Name"][:60], r["Calls"], r["AverageNs"], r["Percentage"])
 PY
