@@ -23,6 +23,11 @@
 //     wave's log in HBM/L2: (key, owning pixel) 8 B + payload (1 - p, g_el, g_az) 16 B - full-line coalesced stores
 //     instead of 64 partial lines (measured: free next to the evaluation).  The log is only read when some pixel of
 //     the tile collected more than K candidates.
+//   * BATCHES ARE PIPELINED.  While a batch of <= 32 faces is evaluated, the scan has already produced the next
+//     batch's hit list (second list in LDS) and its records are in flight into registers; they are committed to LDS
+//     when the next batch starts, behind an explicit s_waitcnt + sched_barrier (left to itself hipcc hoists the next
+//     loads above the wait for the current ones and then waits for both: measured, no gain).  A/B on one box:
+//     3.02 ms vs 3.23 ms without the pipelining, 3.72 ms for the round-1 kernel.
 //   * COOPERATIVE EXACT TOP-K.  Radix select (5 bits per level) over the log with all 64 lanes sweeping it
 //     contiguously; every entry bumps the LDS histogram of ITS pixel; the pixel's owner lane (lane = pixel) scans its
 //     32 buckets and narrows its window; sweeps keep two groups of four 512-byte loads in flight (a sweep with one
@@ -104,13 +109,13 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
     uint32_t* const s_kmax2 = s_selbase + 192;  // ... or the kept entries' largest key (in-loop compaction): never both
     // re-accumulated (sum log2(1 - p), sum g_el, sum g_az, count) of the pixels that went through selection
     float4* const s_acc2 = reinterpret_cast<float4*>(s_selbase + 256);
-    __shared__ int s_hit[kStg2];                   // record index of every staged face
-    __shared__ uint2 s_box[kStg2];                 // its pixel bbox (xl | yl << 16, xh | yh << 16)
+    // two hit lists: while one batch is evaluated the next one is already scanned and its records are in flight
+    __shared__ int s_hit[2 * kStg2];               // record index of every staged face
+    __shared__ uint2 s_box[2 * kStg2];             // its pixel bbox (xl | yl << 16, xh | yh << 16), then (pre, geometry)
     __shared__ float4 s_acc[kCopies * kAccStride]; // (prod (1 - p_k), sum g_el, sum g_az, count) per copy and pixel
     __shared__ uint32_t s_akm[kCopies * kAccStride];  // largest stored key per copy and pixel
     __shared__ uint32_t s_bnd[64];                 // key bound of every pixel
     __shared__ unsigned long long s_hard[64];
-    __shared__ float s_xf[kT2], s_yf[kT2];
 
     WaveLog lg;
     {
@@ -163,11 +168,10 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
         const uint4* __restrict__ scan = reinterpret_cast<const uint4*>(P.ws.scan) + span.base;
 
         __syncthreads();  // the previous item's readers of the LDS state are done
-        if (lane < kT2) {
-            // [P3D] pixel centres in NDC, +X left, +Y up: same expression as the oracle
-            s_xf[lane] = -1.0f + (2.0f * (float)(S - 1 - (x0t + lane)) + 1.0f) / fS;
-            s_yf[lane] = -1.0f + (2.0f * (float)(S - 1 - (y0t + lane)) + 1.0f) / fS;
-        }
+        // [P3D] pixel centre of the pixel this lane owns, in NDC, +X left, +Y up: same expression as the
+        // oracle; a pair lane fetches the centre of ITS pixel from the owning lanes with two cross-lane reads
+        const float own_xf = -1.0f + (2.0f * (float)(S - 1 - xi) + 1.0f) / fS;
+        const float own_yf = -1.0f + (2.0f * (float)(S - 1 - yi) + 1.0f) / fS;
 #pragma unroll
         for (int cpy = 0; cpy < kCopies; ++cpy) {
             s_acc[cpy * kAccStride + myslot] = make_float4(1.f, 0.f, 0.f, 0.f);
@@ -432,40 +436,102 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             return ovf;
         };
 
+        // ---- two-level scan: chunk boxes -> candidate chunks -> their rows (as in occ_raster.hpp) ----------------
+        const int nch = (n + 63) >> 6;
+        const uint4* __restrict__ cbx = reinterpret_cast<const uint4*>(P.ws.rec_cbox) + span.cbox;
+        const uint4 kEmptyBox = make_uint4(0xFFFFu, 0u, 0xFFFFFFFFu, 0u);  // x0 = 65535 > any pixel: never overlaps
+        int cwin = -64;
+        unsigned long long cmask = 0;
+        auto next_chunk = [&]() -> int {
+            while (!cmask) {
+                cwin += 64;
+                if (cwin >= nch) return -1;
+                uint4 cb = kEmptyBox;
+                if (cwin + lane < nch) cb = cbx[cwin + lane];
+                const bool hit = touches(cb);
+                uint32_t km = hit ? cb.z : 0xFFFFFFFFu;
+#pragma unroll
+                for (int mm = 32; mm >= 1; mm >>= 1) km = min(km, (uint32_t)__shfl_xor((int)km, mm, 64));
+                kmin_tile = min(kmin_tile, (uint32_t)__builtin_amdgcn_readfirstlane((int)km));
+                cmask = __ballot(hit && cb.z < thrB);
+            }
+            const int bit = __builtin_ctzll(cmask);
+            cmask &= cmask - 1;
+            return cwin + bit;
+        };
+        int c = next_chunk(), cn = -1;
+        uint4 bb_cur = kEmptyBox, bb_nxt = kEmptyBox;
+        if (c >= 0 && c * 64 + lane < n) bb_cur = scan[c * 64 + lane];
+        unsigned long long m = 0;  // hits of row c not yet staged
+        bool opened = false;       // row c has been balloted (and the next row's boxes requested)
+        // next batch of the scan: up to kStg2 hits into hit list `boff` (0 or kStg2); returns how many
+        auto fill = [&](const int boff) __attribute__((always_inline)) -> int {
+            int cntf = 0;
+            while (cntf < kStg2 && c >= 0) {
+                if (!opened) {
+                    cn = next_chunk();  // the next candidate chunk's row is fetched while this one is worked on
+                    bb_nxt = kEmptyBox;
+                    if (cn >= 0 && cn * 64 + lane < n) bb_nxt = scan[cn * 64 + lane];
+                    m = __ballot(touches(bb_cur) && bb_cur.z < thrB);
+                    opened = true;
+                    OCC_STAT(5, 1);  // chunk rows scanned
+                }
+                if (m) {  // a row may hold more hits than the hit list has room for
+                    const int room = kStg2 - cntf;
+                    const int cnt = __popcll(m);
+                    const int rank = lane_rank(m);
+                    const bool mine = (m >> lane) & 1ull;
+                    if (mine && rank < room) {
+                        s_hit[boff + cntf + rank] = (int)bb_cur.w;
+                        s_box[boff + cntf + rank] = make_uint2(bb_cur.x, bb_cur.y);
+                    }
+                    cntf += min(cnt, room);
+                    m = cnt <= room ? 0ull : __ballot(mine && rank >= room);
+                }
+                if (!m) {
+                    c = cn;
+                    bb_cur = bb_nxt;
+                    opened = false;
+                }
+            }
+            return cntf;
+        };
+
         // ---- one staged batch: records -> LDS, pair expansion, evaluation rounds ------------------------------
         int nst = 0;  // staged faces (wave-uniform)
         // records of the staged faces -> LDS (part-major).  Lane i of a group of 8 fetches part i of one record: the 8
         // loads of a record are one 128-byte line.  kStg2 * 8 / 64 = 4 loads per lane, issued together.
         constexpr int kStageLoads = kStg2 * kRecParts / 64;
-        auto stage_issue = [&](float4 (&r)[kStageLoads]) __attribute__((always_inline)) {
+        auto stage_issue = [&](float4 (&r)[kStageLoads], const int boff, const int cntf) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < kStageLoads; ++i) {
                 const int idx = lane + 64 * i, k = idx >> 3, part = idx & 7;
-                r[i] = (idx < nst * kRecParts && part < kParts) ? recs4[(size_t)s_hit[k] * kRecParts + part] : make_float4(0, 0, 0, 0);
+                r[i] = (idx < cntf * kRecParts && part < kParts) ? recs4[(size_t)s_hit[boff + k] * kRecParts + part] : make_float4(0, 0, 0, 0);
             }
         };
-        auto stage_commit = [&](const float4 (&r)[kStageLoads]) __attribute__((always_inline)) {
+        auto stage_commit = [&](const float4 (&r)[kStageLoads], const int cntf) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < kStageLoads; ++i) {
                 const int idx = lane + 64 * i, k = idx >> 3, part = idx & 7;
-                if (idx < nst * kRecParts && part < kParts) s_rec[part * kStgPad + k] = r[i];
+                if (idx < cntf * kRecParts && part < kParts) s_rec[part * kStgPad + k] = r[i];
             }
         };
-        auto stage_records = [&]() __attribute__((always_inline)) {
+        float4 rstage[kStageLoads];  // records of the NEXT batch in flight
+        int boff = 0;                // hit list of the CURRENT batch
+        auto stage_records = [&]() __attribute__((always_inline)) {  // (rare) put the current batch's records back
             float4 r[kStageLoads];
-            stage_issue(r);
-            stage_commit(r);
+            stage_issue(r, boff, nst);
+            stage_commit(r, nst);
         };
-        auto process_batch = [&]() {
+        // One batch: its records (requested a batch ago) go to LDS, pair counts, prefix sum, pair map; then the NEXT
+        // batch is scanned and its record loads are issued, to fly during this batch's evaluation rounds.
+        auto process_batch = [&]() __attribute__((always_inline)) -> int {
             OCC_T(2);  // scan (chunk boxes, rows, hit lists)
             __syncthreads();
-            // the record loads fly while the pair counts, their prefix sum and the first window's descriptors are made
-            float4 rstage[kStageLoads];
-            stage_issue(rstage);
             // pixels of this lane's face inside the tile: pair count, prefix sum over the staged faces
             int c = 0, cx0 = 0, cy0 = 0, cw = 1;
             if (lane < nst) {
-                const uint2 bb = s_box[lane];
+                const uint2 bb = s_box[boff + lane];
                 cx0 = max((int)(bb.x & 0xFFFFu), x0t);
                 cy0 = max((int)(bb.x >> 16), y0t);
                 const int cx1 = min((int)(bb.y & 0xFFFFu), x0t + kT2 - 1), cy1 = min((int)(bb.y >> 16), y0t + kT2 - 1);
@@ -493,7 +559,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 __builtin_amdgcn_wave_barrier();
                 if (lane < nst) {
                     const uint32_t inv15 = (32768u + (uint32_t)cw - 1u) / (uint32_t)cw;
-                    s_box[lane] = make_uint2((uint32_t)pre, (uint32_t)(cx0 - x0t) | ((uint32_t)(cy0 - y0t) << 3) | ((uint32_t)(cw - 1) << 6) | (inv15 << 16));
+                    s_box[boff + lane] = make_uint2((uint32_t)pre, (uint32_t)(cx0 - x0t) | ((uint32_t)(cy0 - y0t) << 3) | ((uint32_t)(cw - 1) << 6) | (inv15 << 16));
                     if (lane > 0) s_flag[pre] = 1;
                 }
             };
@@ -503,9 +569,20 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             {
                 OCC_T(3);  // pair counts
                 mark_pairs();
-                stage_commit(rstage);
+                // the records of THIS batch were requested a whole batch ago: wait for them here, explicitly, and keep
+                // the compiler from moving the next batch's loads above this wait (it would then wait for those too)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                stage_commit(rstage, nst);
                 __syncthreads();
-                OCC_T(4);  // pair map
+                __builtin_amdgcn_sched_barrier(0);
+                OCC_T(4);  // pair map + record commit
+            }
+            // scan ahead: the next batch's hit list, its record loads fly while this batch is evaluated
+            const int nst_next = fill(boff ^ kStg2);
+            if (nst_next) stage_issue(rstage, boff ^ kStg2, nst_next);
+            OCC_T(2);
+            {
                 if (SOFT && nlog + ptot > OCC_LOG_CAP) {
                     // rare: the log could fill up inside this batch -> keep every overflowing pixel's K nearest,
                     // compact the log, go on with tighter bounds
@@ -532,14 +609,14 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     const unsigned long long mk = __ballot(mark);
                     const int f = live ? fbase + lane_rank(mk) + (mark ? 1 : 0) : 0;
                     fbase += __popcll(mk);
-                    const uint2 fg = s_box[f];
+                    const uint2 fg = s_box[boff + f];
                     const uint32_t jj = live ? (uint32_t)(p0 + lane) - fg.x : 0u;
                     const uint32_t wq = (jj * (fg.y >> 16)) >> 15;  // jj / width (exact for jj < 64, width <= 8)
                     const uint32_t px_ = (fg.y & 7u) + (jj - wq * (((fg.y >> 6) & 7u) + 1u)), py_ = ((fg.y >> 3) & 7u) + wq;
                     const uint32_t d = (py_ << 3) | px_;
                     const int pix = (int)d;
-                    const int j = s_hit[f];
-                    const float xf = s_xf[d & 7], yf = s_yf[(d >> 3) & 7];
+                    const int j = s_hit[boff + f];
+                    const float xf = __shfl(own_xf, (int)(d & 7u), 64), yf = __shfl(own_yf, (int)(d & 56u), 64);
                     const float4* rs = &s_rec[f];
                     Cand c1;
                     eval_face<SOFT, GRAD, false>(rs[0], rs[kStgPad], rs[2 * kStgPad], rs[3 * kStgPad],
@@ -624,7 +701,6 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             }
             __syncthreads();
             OCC_T(5);  // evaluation rounds
-            nst = 0;
             // Front-to-back pruning (SURVEY A.4 keeps the K smallest depths): once a pixel holds >= K candidates its
             // largest stored key bounds its K-th nearest from above, later candidates at or beyond it are dropped
             // unseen; once that holds for all 64 pixels (and every pixel has a hard face) whole faces / chunks whose
@@ -646,67 +722,18 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             for (int mm = 32; mm >= 1; mm >>= 1) bound = max(bound, (uint32_t)__shfl_xor((int)bound, mm, 64));
             thrB = (uint32_t)__builtin_amdgcn_readfirstlane((int)bound);
             OCC_T(6);  // pruning bounds
+            return nst_next;
         };
 
-        // ---- two-level scan: chunk boxes -> candidate chunks -> their rows (as in occ_raster.hpp) ----------------
-        const int nch = (n + 63) >> 6;
-        const uint4* __restrict__ cbx = reinterpret_cast<const uint4*>(P.ws.rec_cbox) + span.cbox;
-        const uint4 kEmptyBox = make_uint4(0xFFFFu, 0u, 0xFFFFFFFFu, 0u);  // x0 = 65535 > any pixel: never overlaps
-        int cwin = -64;
-        unsigned long long cmask = 0;
-        auto next_chunk = [&]() -> int {
-            while (!cmask) {
-                cwin += 64;
-                if (cwin >= nch) return -1;
-                uint4 cb = kEmptyBox;
-                if (cwin + lane < nch) cb = cbx[cwin + lane];
-                const bool hit = touches(cb);
-                uint32_t km = hit ? cb.z : 0xFFFFFFFFu;
-#pragma unroll
-                for (int mm = 32; mm >= 1; mm >>= 1) km = min(km, (uint32_t)__shfl_xor((int)km, mm, 64));
-                kmin_tile = min(kmin_tile, (uint32_t)__builtin_amdgcn_readfirstlane((int)km));
-                cmask = __ballot(hit && cb.z < thrB);
-            }
-            const int bit = __builtin_ctzll(cmask);
-            cmask &= cmask - 1;
-            return cwin + bit;
-        };
-        int c = next_chunk(), cn = -1;
-        uint4 bb_cur = kEmptyBox, bb_nxt = kEmptyBox;
-        if (c >= 0 && c * 64 + lane < n) bb_cur = scan[c * 64 + lane];
-        unsigned long long m = 0;  // hits of row c not yet staged
-        bool opened = false;       // row c has been balloted (and the next row's boxes requested)
-        for (;;) {
-            while (nst < kStg2 && c >= 0) {
-                if (!opened) {
-                    cn = next_chunk();  // the next candidate chunk's row is fetched while this one is worked on
-                    bb_nxt = kEmptyBox;
-                    if (cn >= 0 && cn * 64 + lane < n) bb_nxt = scan[cn * 64 + lane];
-                    m = __ballot(touches(bb_cur) && bb_cur.z < thrB);
-                    opened = true;
-                    OCC_STAT(5, 1);  // chunk rows scanned
-                }
-                if (m) {  // a row may hold more hits than the staging buffer has room for
-                    const int room = kStg2 - nst;
-                    const int cnt = __popcll(m);
-                    const int rank = lane_rank(m);
-                    const bool mine = (m >> lane) & 1ull;
-                    if (mine && rank < room) {
-                        s_hit[nst + rank] = (int)bb_cur.w;
-                        s_box[nst + rank] = make_uint2(bb_cur.x, bb_cur.y);
-                    }
-                    nst += min(cnt, room);
-                    m = cnt <= room ? 0ull : __ballot(mine && rank >= room);
-                }
-                if (!m) {
-                    c = cn;
-                    bb_cur = bb_nxt;
-                    opened = false;
-                }
-            }
-            if (nst == 0) break;
-            process_batch();
+        nst = fill(0);
+        if (nst) stage_issue(rstage, 0, nst);
+        while (nst) {
+            const int nst_next = process_batch();
+            boff ^= kStg2;
+            nst = nst_next;
         }
+
+
         OCC_T(2);
 
         // ---- per-pixel results (lane = pixel) ---------------------------------------------------------------------
