@@ -9,7 +9,6 @@ for l in sys.stdin:
         j = json.loads(l); print('$name', 'raster %.3f ms' % j['roofline']['avg_launch_ms'], 'step %.3f ms' % j['ms_per_step'], '%.0f steps/s' % j['value'])"
 }
 for r in 1 2 3; do
-  run newC X=1
-  run newP OCC_HIP_LIB=$PWD/build/dbg2/libocc_vp.so
-  run newC_wpc11 OCC_WAVES_PER_CU=11
+  run newP X=1
+  run newL OCC_HIP_LIB=$PWD/build/dbg2/libocc_vl.so
 done
