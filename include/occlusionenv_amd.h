@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define OCC_ABI_VERSION 4
+#define OCC_ABI_VERSION 5
 
 /* return codes */
 #define OCC_OK 0
@@ -132,6 +132,15 @@ typedef struct OccWorkspace {
      * (3*n_env+1 int64) is filled by occ_render.  NULL = fixed stride rec_cap per (env, object). */
     int64_t* rec_off;
     int64_t rec_total;
+    /* Optional work-item ORDER of occ_raster2_kernel (NULL = rect order): the tiles of all objects sorted by an
+     * estimate of their cost (faces whose pixel bbox touches the tile), heaviest first inside every XCD queue, so
+     * that the longest tiles start first and the launch does not end on a few stragglers.  u32 words:
+     *   [0..8] first item of every XCD queue and the total, [16 + 32 q + c] tiles of cost class c in queue q,
+     *   [512 + 32 (env*3+obj) + c] where the object's class-c tiles start inside the class,
+     *   then (n_env,3,T) per tile: rank inside the object's class << 5 | class   (T = (S/8)^2 tiles per image),
+     *   then (n_env*3*T) items (env*3+obj, tile index inside the object's rect), 8 B each.
+     * occ_render zeroes the first 512 words. */
+    uint32_t* order;
 } OccWorkspace;
 
 typedef struct OccWorkspaceSizes {
@@ -140,6 +149,7 @@ typedef struct OccWorkspaceSizes {
         obj_hrec_bytes, rec_cbox_bytes, scan_bytes;
     int32_t n_slots; /* recommended persistent-wave count for this device */
     size_t rec_off_bytes;
+    size_t order_bytes;
 } OccWorkspaceSizes;
 
 /* Outputs of one batched render (device pointers; any may be NULL if the flag is off). */

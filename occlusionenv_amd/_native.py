@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OCC_HIP_LIB") or os.path.join(_HERE, "libocc_hip.so")
 
 # layout constants (must match include/occlusionenv_amd.h)
-ABI_VERSION = 4
+ABI_VERSION = 5
 CAM_STRIDE = 48
 REC_STRIDE = 32
 TILE = 8
@@ -70,6 +70,7 @@ class OccWorkspace(C.Structure):
         ("n_slots", C.c_int32),
         ("rec_off", C.c_void_p),
         ("rec_total", C.c_int64),
+        ("order", C.c_void_p),
     ]
 
 
@@ -92,6 +93,7 @@ class OccWorkspaceSizes(C.Structure):
         ("scan_bytes", C.c_size_t),
         ("n_slots", C.c_int32),
         ("rec_off_bytes", C.c_size_t),
+        ("order_bytes", C.c_size_t),
     ]
 
 

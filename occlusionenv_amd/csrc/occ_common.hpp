@@ -17,6 +17,22 @@ typedef const __attribute__((address_space(4))) int* ciptr;
 __device__ __forceinline__ cfptr as_const(const float* p) { return (cfptr)(uintptr_t)p; }
 __device__ __forceinline__ ciptr as_const(const int* p) { return (ciptr)(uintptr_t)p; }
 
+// Layout of OccWorkspace.order (u32 words, see include/occlusionenv_amd.h): the work-item order of occ_raster2_kernel
+constexpr int kOrdCounts = 16;    // [16 + 32 q + c]: tiles of cost class c in XCD queue q
+constexpr int kOrdClasses = 32;
+constexpr int kOrdBlk = 512;      // [512 + 32 eo + c]: start of object eo's class-c tiles inside the class
+__host__ __device__ __forceinline__ size_t ord_tiles_word(int n_env) { return (size_t)kOrdBlk + (size_t)n_env * 3 * kOrdClasses; }
+__host__ __device__ __forceinline__ size_t ord_items_word(int n_env, int img) {
+    return ord_tiles_word(n_env) + (size_t)n_env * 3 * (img / 8) * (img / 8);
+}
+// cost class of a tile that c faces touch: two classes per octave, 0 = empty
+__device__ __forceinline__ int ord_class(uint32_t c) {
+    if (c == 0u) return 0;
+    const int fl = 31 - __builtin_clz(c);
+    const int half = fl > 0 ? (int)((c >> (fl - 1)) & 1u) : 0;
+    return min(kOrdClasses - 1, 1 + 2 * fl + half);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);

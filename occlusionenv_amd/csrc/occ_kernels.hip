@@ -104,9 +104,10 @@ extern "C" int occ_debug_stats(unsigned long long* out8) {
 #endif
 
 #ifdef OCC_DBG_TIME
-extern "C" int occ_debug_time(unsigned long long* out16) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(occ::g_dbg_time), 16 * sizeof(unsigned long long)) != hipSuccess) return 2;
-    unsigned long long z[16] = {0};
+extern "C" int occ_debug_time(unsigned long long* out32) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(occ::g_dbg_time), 32 * sizeof(unsigned long long)) != hipSuccess) return 2;
+    unsigned long long z[32] = {0};
+    z[16] = ~0ull;
     return hipMemcpyToSymbol(HIP_SYMBOL(occ::g_dbg_time), z, sizeof(z)) == hipSuccess ? 0 : 2;
 }
 #endif
@@ -161,6 +162,10 @@ extern "C" int occ_workspace_query(const OccScene* scene, int n_slots, OccWorksp
     out->status_bytes = N * sizeof(int32_t);
     out->n_slots = n_slots;
     out->rec_off_bytes = (N * 3 + 1) * sizeof(int64_t);
+    {   // work-item order: header + per-object class offsets + per-tile (rank, class) + the item list
+        const size_t T = (size_t)(scene->img / 8) * (scene->img / 8);
+        out->order_bytes = (kOrdBlk + N * 3 * kOrdClasses + N * 3 * T * 3) * sizeof(uint32_t);
+    }
     return OCC_OK;
 }
 
@@ -200,6 +205,16 @@ static int raster_variant() {
     return v;
 }
 
+// OCC_ORDER=0: work items of occ_raster2_kernel in rect order even when the workspace has an order buffer (A/B timing)
+static bool order_enabled() {
+    static int v = 0;
+    if (!v) {
+        const char* e = getenv("OCC_ORDER");
+        v = (e && e[0] == '0') ? 1 : 2;
+    }
+    return v == 2;
+}
+
 static bool dbg_sync_on() {
     static int on = -1;
     if (on < 0) {
@@ -234,6 +249,10 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(ws->queue, 0, 8 * 16 * sizeof(uint32_t), st) != hipSuccess) return OCC_ERR_LAUNCH;
     const int N = scene->n_env;
+    const int rv = raster_variant();
+    OccWorkspace wsv = *ws;  // the kernels' view of the workspace
+    if (rv != 2 || !order_enabled()) wsv.order = nullptr;
+    if (wsv.order && hipMemsetAsync(wsv.order, 0, kOrdBlk * sizeof(uint32_t), st) != hipSuccess) return OCC_ERR_LAUNCH;
     if (ws->rec_off) {
         if (ws->rec_total <= 0 || (ws->rec_total & 63)) return OCC_ERR_ARG;
         hipLaunchKernelGGL(occ_recoff_kernel, dim3(1), dim3(1024), 0, st, *scene, (long long*)ws->rec_off,
@@ -241,9 +260,9 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
         OCC_DBG_SYNC("recoff");
     }
     if (grad)
-        hipLaunchKernelGGL(occ_setup_kernel<true>, dim3(N * 3), dim3(256), 0, st, *scene, cam, *ws);
+        hipLaunchKernelGGL(occ_setup_kernel<true>, dim3(N * 3), dim3(256), 0, st, *scene, cam, wsv);
     else
-        hipLaunchKernelGGL(occ_setup_kernel<false>, dim3(N * 3), dim3(256), 0, st, *scene, cam, *ws);
+        hipLaunchKernelGGL(occ_setup_kernel<false>, dim3(N * 3), dim3(256), 0, st, *scene, cam, wsv);
     OCC_DBG_SYNC("setup");
     if (scene->rec_cap >= kSortMin) {
         // dense objects only: front-to-back scan order (LDS sort buffer: 8192 keys = 64 KiB)
@@ -255,14 +274,18 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
     if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
     RasterParams P;
     P.sc = *scene;
-    P.ws = *ws;
+    P.ws = wsv;
     P.out = *out;
     P.cam = cam;
     P.K = faces_per_pixel;
     P.ntx = scene->img / OCC_TILE;
-    const int rv = raster_variant();
-    hipLaunchKernelGGL(occ_scan_kernel, dim3(1), dim3(1024), 0, st, ws->objrect, ws->nrec, ws->offsets, N, rv == 2 ? 1 : 0);
-    OCC_DBG_SYNC("scan");
+    if (wsv.order) {
+        hipLaunchKernelGGL(occ_order_kernel, dim3(N * 3), dim3(64), 0, st, ws->objrect, ws->nrec, wsv.order, N, scene->img);
+        OCC_DBG_SYNC("order");
+    } else {
+        hipLaunchKernelGGL(occ_scan_kernel, dim3(1), dim3(1024), 0, st, ws->objrect, ws->nrec, ws->offsets, N, rv == 2 ? 1 : 0);
+        OCC_DBG_SYNC("scan");
+    }
     if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
     const dim3 grid(ws->n_slots), block(64);
     const bool prof = g_prof_on && g_prof_n < kProfMax;

@@ -371,6 +371,59 @@ __global__ __launch_bounds__(1024) void occ_scan_kernel(const int* __restrict__ 
     if (tid == 0) offsets[M] = s_carry;
 }
 
+// Work-item list of occ_raster2_kernel in cost order (OccWorkspace.order): one wave per (env, object).  The setup
+// kernel has left, per tile, its cost class and rank among the object's tiles of that class, per object where its share
+// of every class starts, and per XCD queue the class totals.  Queue q's items are laid out heaviest class first; item
+// position = queue start + tiles of heavier classes + object's start in the class + rank.  Block 0 also publishes the
+// queue boundaries.  (Positions inside a class depend on the order in which the setup blocks reserved their share:
+// the ORDER of items may differ between runs, the results cannot - every item writes only its own pixels.)
+__global__ __launch_bounds__(64) void occ_order_kernel(const int* __restrict__ objrect, const int* __restrict__ nrec,
+                                                       uint32_t* __restrict__ order, int n_env, int img) {
+    __shared__ uint32_t s_base[kOrdClasses];
+    const int eo = blockIdx.x, env = eo / 3, q = env & 7, lane = threadIdx.x;
+    const uint32_t* counts = order + kOrdCounts;
+    // queue totals: lane l < 8 sums queue l (32 loads; 256 words, L2-resident)
+    uint32_t qt = 0u;
+    if (lane < 8)
+        for (int c = 0; c < kOrdClasses; ++c) qt += counts[lane * kOrdClasses + c];
+    uint32_t qincl = qt;  // inclusive prefix over the queues
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)qincl, d, 64);
+        if (lane >= d) qincl += t;
+    }
+    if (eo == 0 && lane < 8) {
+        order[lane + 1] = qincl;
+        if (lane == 0) order[0] = 0u;
+    }
+    const uint32_t qstart = (uint32_t)__shfl((int)(qincl - qt), q, 64);
+    // classes of my queue, heaviest first: tiles of the classes above c
+    const uint32_t v = lane < kOrdClasses ? counts[q * kOrdClasses + lane] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < kOrdClasses; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    const uint32_t tot = (uint32_t)__shfl((int)incl, kOrdClasses - 1, 64);
+    if (lane < kOrdClasses) s_base[lane] = qstart + (tot - incl) + order[kOrdBlk + (size_t)eo * kOrdClasses + lane];
+    __syncthreads();
+    if (nrec[eo] <= 0) return;
+    const int x0 = objrect[4 * eo], y0 = objrect[4 * eo + 1], x1 = objrect[4 * eo + 2], y1 = objrect[4 * eo + 3];
+    if (x1 < x0 || y1 < y0 || x0 < 0 || y0 < 0) return;
+    const int ntile = ((x1 >> 1) - (x0 >> 1) + 1) * ((y1 >> 1) - (y0 >> 1) + 1);
+    const int T = (img / 8) * (img / 8);
+    if (ntile > T) return;  // never true for a sane rect
+    const uint32_t* __restrict__ tord = order + ord_tiles_word(n_env) + (size_t)eo * T;
+    uint2* __restrict__ items = reinterpret_cast<uint2*>(order + ord_items_word(n_env, img));
+    const uint32_t cap = (uint32_t)n_env * 3u * (uint32_t)T;
+    for (int local = lane; local < ntile; local += 64) {
+        const uint32_t w = tord[local];
+        const uint32_t pos = s_base[w & 31u] + (w >> 5);
+        if (pos < cap) items[pos] = make_uint2((uint32_t)eo, (uint32_t)local);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // raster kernel: one persistent wave64 per work item (env, object, 4x4-pixel block inside the object's rect)
 // ------------------------------------------------------------------------------------------

@@ -71,13 +71,24 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {  // set bits of
 }
 
 #ifdef OCC_DBG_TIME  // diagnostic build only: shader cycles per phase of the raster kernel, summed over waves
-__device__ unsigned long long g_dbg_time[16];
-#define OCC_T_DECL unsigned long long t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long t_last = __builtin_amdgcn_s_memtime()
+// [0..15] cycles per phase; [16] earliest wave start, [17] latest wave end, [18] sum of wave ends, [19] waves,
+// [20] sum / [21] count / [22] max of item times with an overflowing pixel, [23] sum / [24] count of the others
+// ([16..24] in s_memrealtime ticks, 100 MHz)
+__device__ unsigned long long g_dbg_time[32];
+#define OCC_T_DECL unsigned long long t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long t_last = __builtin_amdgcn_s_memtime(); \
+    const unsigned long long t_w0 = __builtin_amdgcn_s_memrealtime(); unsigned long long t_item = t_w0, t_os = 0, t_on = 0, t_om = 0, t_ns = 0, t_nn = 0
+#define OCC_T_ITEM(heavy) do { const unsigned long long t_n = __builtin_amdgcn_s_memrealtime(), d_ = t_n - t_item; t_item = t_n; \
+        if (heavy) { t_os += d_; t_on += 1; t_om = d_ > t_om ? d_ : t_om; } else { t_ns += d_; t_nn += 1; } } while (0)
 #define OCC_T(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
-#define OCC_T_FLUSH do { if (lane == 0) { for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_dbg_time[i_], t_acc[i_]); } } while (0)
+#define OCC_T_FLUSH do { if (lane == 0) { for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_dbg_time[i_], t_acc[i_]); \
+        const unsigned long long t_e = __builtin_amdgcn_s_memrealtime(); \
+        atomicMin(&g_dbg_time[16], t_w0); atomicMax(&g_dbg_time[17], t_e); atomicAdd(&g_dbg_time[18], t_e); atomicAdd(&g_dbg_time[19], 1ull); \
+        atomicAdd(&g_dbg_time[20], t_os); atomicAdd(&g_dbg_time[21], t_on); atomicMax(&g_dbg_time[22], t_om); \
+        atomicAdd(&g_dbg_time[23], t_ns); atomicAdd(&g_dbg_time[24], t_nn); } } while (0)
 #else
 #define OCC_T_DECL do { } while (0)
 #define OCC_T(i) do { } while (0)
+#define OCC_T_ITEM(heavy) do { } while (0)
 #define OCC_T_FLUSH do { } while (0)
 #endif
 
@@ -124,6 +135,9 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
         lg.kt = reinterpret_cast<uint2*>(base + (size_t)OCC_LOG_CAP * 16);
     }
     ciptr offs = as_const(P.ws.offsets);
+    ciptr ord = as_const(reinterpret_cast<const int*>(P.ws.order));  // null: rect order through offs
+    const uint2* __restrict__ ord_items =
+        reinterpret_cast<const uint2*>(P.ws.order + (P.ws.order ? ord_items_word(P.sc.n_env, S) : 0));
     const int mq = xcd_slots(P.sc.n_env), MP = 8 * mq;
     const int my_xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;  // steers which queue is drained first only
     int qround = 0;
@@ -135,7 +149,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
         int item = -1;
         while (qround < 8) {
             const int qq = (my_xcc + qround) & 7;
-            const int qbeg = offs[qq * mq], qend = offs[(qq + 1) * mq];
+            const int qbeg = ord ? ord[qq] : offs[qq * mq], qend = ord ? ord[qq + 1] : offs[(qq + 1) * mq];
             int t = qend;
             if (lane == 0 && qbeg < qend) t = qbeg + (int)atomicAdd(P.ws.queue + qq * 16, 1u);
             t = __builtin_amdgcn_readfirstlane(t);
@@ -147,14 +161,21 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
         }
         if (item < 0) break;
         OCC_T(0);  // dequeue
-        int lo = 0, hi = MP;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (offs[mid] <= item) lo = mid; else hi = mid;
+        int eo, local;
+        if (ord) {  // cost order (occ_order_kernel): the item list names the tile
+            const uint2 it = ord_items[item];
+            eo = __builtin_amdgcn_readfirstlane((int)it.x);
+            local = __builtin_amdgcn_readfirstlane((int)it.y);
+        } else {    // rect order: find the (env, object) whose item range holds this one
+            int lo = 0, hi = MP;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (offs[mid] <= item) lo = mid; else hi = mid;
+            }
+            eo = perm_to_eo(lo, mq, P.sc.n_env);
+            local = item - offs[lo];
         }
-        const int eo = perm_to_eo(lo, mq, P.sc.n_env);
-        if (eo < 0 || eo >= 3 * P.sc.n_env) continue;
-        const int local = item - offs[lo];
+        if (eo < 0 || eo >= 3 * P.sc.n_env || local < 0) continue;
         ciptr rect = as_const(P.ws.objrect + eo * 4);  // in OCC_BLOCK (4-pixel) units; tiles are 2 x 2 blocks
         const int tx0 = rect[0] >> 1, ty0 = rect[1] >> 1, tw = (rect[2] >> 1) - tx0 + 1;
         const int x0t = (tx0 + local % tw) * kT2, y0t = (ty0 + local / tw) * kT2;
@@ -755,6 +776,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             if (__ballot(ovf)) selected = select_topk(false);  // more than K candidates: keep the K nearest in z, A.4
 #endif
             OCC_T(8);  // final selection
+            OCC_T_ITEM(__ballot(ovf) != 0ull);
             float prod, sge, sga;
             if (selected) {
                 const float4 a2 = s_acc2[lane];

@@ -421,6 +421,11 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
     __shared__ int s_rect[4];
     __shared__ uint2 s_box[256];  // pixel bbox of this thread's face as its ONE visibility evaluation found it
     __shared__ float4 s_rec[4 * 64 * kRecPad];  // per wave: the records of one round, staged for coalesced stores
+    // work-item order (ws.order): faces per cell of a <= 16 x 16 grid over the image (cell = 8x8 tile, or a square of
+    // tiles when the image has more than 16 tiles a side), faces too large to count cell by cell, tiles per cost class
+    __shared__ uint32_t s_tcost[256];
+    __shared__ uint32_t s_cls[kOrdClasses];
+    __shared__ uint32_t s_big;
     // (LDS stride 9 parts = 36 dwords: a 32-dword stride would put every lane's write on the same banks)
     const int eo = blockIdx.x;  // env*3 + object
     const int env = eo / 3;
@@ -447,6 +452,15 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
     const float* __restrict__ pool_verts = sc.pool_verts;
     const RecSpan span = rec_span(ws, sc.rec_cap, eo);
     const int S = sc.img, rec_cap = span.cap;
+    const bool ordered = ws.order != nullptr;
+    const int tiles_side = S / 8;
+    int cs = 0;  // tiles per cell side = 1 << cs
+    while ((tiles_side >> cs) > 16) ++cs;
+    if (ordered) {
+        s_tcost[tid] = 0u;
+        if (tid < kOrdClasses) s_cls[tid] = 0u;
+        if (tid == 0) s_big = 0u;
+    }
     if (tid == 0) {
         s_rect[0] = 1 << 20;
         s_rect[1] = 1 << 20;
@@ -584,6 +598,16 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
                 }
                 rx0 = min(rx0, x0); ry0 = min(ry0, y0);
                 rx1 = max(rx1, x1); ry1 = max(ry1, y1);
+                if (ordered) {  // this face in the cost of every cell its bbox touches (a handful)
+                    const int cx0 = max(x0 >> (1 + cs), 0), cx1 = min(x1 >> (1 + cs), 15);
+                    const int cy0 = max(y0 >> (1 + cs), 0), cy1 = min(y1 >> (1 + cs), 15);
+                    if ((cx1 - cx0 + 1) * (cy1 - cy0 + 1) <= 16) {
+                        for (int cy = cy0; cy <= cy1; ++cy)
+                            for (int cx = cx0; cx <= cx1; ++cx) atomicAdd(&s_tcost[cy * 16 + cx], (uint32_t)cnt);
+                    } else {
+                        atomicAdd(&s_big, (uint32_t)cnt);  // counted for every tile
+                    }
+                }
             } else {
                 overflow = true;
             }
@@ -626,6 +650,26 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
         const int nr = min(total, rec_cap);
         __syncthreads();  // scan[] of the whole object written (and s_rect complete)
         chunk_boxes(scan, reinterpret_cast<uint4*>(ws.rec_cbox) + span.cbox, nr, wave, lane);
+    }
+    if (ordered && total > 0 && total <= rec_cap && s_rect[2] >= s_rect[0] && s_rect[3] >= s_rect[1] && s_rect[0] >= 0 && s_rect[1] >= 0) {
+        // every tile of the object's rect (= one work item of occ_raster2_kernel) gets its cost class and a rank
+        // among the object's tiles of that class; the class totals of the XCD queue grow by this object's counts and
+        // tell where its share of each class starts (occ_order_kernel turns this into the item list)
+        const int tx0 = s_rect[0] >> 1, ty0 = s_rect[1] >> 1;
+        const int tw = (s_rect[2] >> 1) - tx0 + 1, th = (s_rect[3] >> 1) - ty0 + 1;
+        uint32_t* __restrict__ tord = ws.order + ord_tiles_word(sc.n_env) + (size_t)eo * tiles_side * tiles_side;
+        const uint32_t big = s_big;
+        for (int local = tid; local < tw * th; local += 256) {
+            const int tx = tx0 + local % tw, ty = ty0 + local / tw;
+            const int cls = ord_class(s_tcost[min(ty >> cs, 15) * 16 + min(tx >> cs, 15)] + big);
+            tord[local] = (atomicAdd(&s_cls[cls], 1u) << 5) | (uint32_t)cls;
+        }
+        __syncthreads();
+        if (tid < kOrdClasses) {
+            const uint32_t cnt = s_cls[tid];
+            ws.order[kOrdBlk + (size_t)eo * kOrdClasses + tid] =
+                cnt ? atomicAdd(&ws.order[kOrdCounts + (env & 7) * kOrdClasses + tid], cnt) : 0u;
+        }
     }
     if (tid == 0) {
         // more records than the span holds (OCC_STATUS_REC_OVERFLOW is set): the object is left out altogether

@@ -194,7 +194,8 @@ class OcclusionEngine:
             t = dict(nrec=buf(sizes.nrec_bytes), objrect=buf(sizes.objrect_bytes), queue=buf(sizes.queue_bytes),
                      lists=buf(sizes.lists_bytes), partials=buf(sizes.partials_bytes), status=buf(sizes.status_bytes),
                      offsets=buf(sizes.offsets_bytes), obj_alpha=buf(sizes.obj_alpha_bytes),
-                     obj_grad=buf(sizes.obj_grad_bytes), obj_hz=buf(sizes.obj_hz_bytes), obj_hrec=buf(sizes.obj_hrec_bytes))
+                     obj_grad=buf(sizes.obj_grad_bytes), obj_hz=buf(sizes.obj_hz_bytes), obj_hrec=buf(sizes.obj_hrec_bytes),
+                     order=buf(sizes.order_bytes))
             ws = nat.OccWorkspace()
             for k, v in t.items():
                 setattr(ws, k, v.data_ptr())

@@ -1,4 +1,5 @@
 #!/bin/bash
+# one-box interleaved A/B of two configurations of the raster path (env toggles or OCC_HIP_LIB builds)
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 run() {
   name=$1; shift
@@ -9,6 +10,6 @@ for l in sys.stdin:
         j = json.loads(l); print('$name', 'raster %.3f ms' % j['roofline']['avg_launch_ms'], 'step %.3f ms' % j['ms_per_step'], '%.0f steps/s' % j['value'])"
 }
 for r in 1 2 3; do
-  run newP X=1
-  run newL OCC_HIP_LIB=$PWD/build/dbg2/libocc_vl.so
+  run rect OCC_ORDER=0
+  run cost OCC_ORDER=1
 done

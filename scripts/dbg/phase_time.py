@@ -18,7 +18,7 @@ for mesh, img in [("synthetic", 128), ("mixed", 128), ("teapot", 128)]:
     a = case["actions"].cuda().requires_grad_(True)
     eng.step(a)
     torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * 16)()
+    buf = (ctypes.c_ulonglong * 32)()
     lib.occ_debug_time(buf)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
@@ -29,4 +29,10 @@ for mesh, img in [("synthetic", 128), ("mixed", 128), ("teapot", 128)]:
     tot = float(sum(buf[:16]))
     print(mesh, img, "N", N, "step %.2f ms; wave-cycles %.3e:" % (ev0.elapsed_time(ev1), tot),
           "  ".join("%s %.1f%%" % (n, 100.0 * buf[i] / tot) for i, n in enumerate(names)), flush=True)
+    t0, t1, tsum, nw = buf[16], buf[17], buf[18], max(buf[19], 1)
+    span = (t1 - t0) / 100.0  # us
+    print("   waves %d: span %.0f us, mean wave end at %.0f us -> %.1f%% of the wave-slot time is after a wave's end;"
+          % (nw, span, (tsum / nw - t0) / 100.0, 100.0 * (1.0 - (tsum / nw - t0) / max(t1 - t0, 1))),
+          "items with selection: %d, mean %.0f us, max %.0f us; others: %d, mean %.1f us"
+          % (buf[21], buf[20] / max(buf[21], 1) / 100.0, buf[22] / 100.0, buf[24], buf[23] / max(buf[24], 1) / 100.0), flush=True)
     del eng

@@ -242,3 +242,35 @@ def test_step_through_the_degenerate_camera_pose():
     # DIRECTION turns by O(1) per 4e-8 of camera motion, so d/d(el, az) amplifies last-bit differences by ~1e7
     # (PyTorch3D's autograd does the same)
     assert torch.isfinite(a.grad).all() and torch.isfinite(ao.grad).all()
+
+
+_ORDER_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from tests.parity_utils import make_case, run_engine
+case = make_case(48, 321, "mixed", az_range=2.5)
+r = run_engine(case, 128)
+torch.save({k: r[k] for k in ("obs", "alphas", "fs", "loss", "grad", "obj_grad")}, sys.argv[2])
+"""
+
+
+def test_results_do_not_depend_on_the_work_item_order(tmp_path):
+    """occ_raster2_kernel takes its tiles heaviest first (OccWorkspace.order; positions inside a cost class depend on
+    the order in which the setup blocks reserved them, so the ORDER of items varies from launch to launch): every
+    output must be bit-identical between two launches and against the rect order (OCC_ORDER=0, a fresh process)."""
+    from tests.parity_utils import make_case, run_engine
+
+    keys = ("obs", "alphas", "fs", "loss", "grad", "obj_grad")
+    runs = []
+    for _ in range(2):
+        r = run_engine(make_case(48, 321, "mixed", az_range=2.5), 128)
+        runs.append({k: r[k] for k in keys})
+        del r
+    for k in keys:
+        assert torch.equal(runs[0][k], runs[1][k]), k
+    out = tmp_path / "rect.pt"
+    env = dict(os.environ, OCC_ORDER="0")
+    subprocess.run([sys.executable, "-c", _ORDER_SCRIPT, ROOT, str(out)], check=True, env=env, timeout=600)
+    rect = torch.load(out)
+    for k in keys:
+        assert torch.equal(runs[0][k], rect[k]), k
