@@ -104,10 +104,11 @@ extern "C" int occ_debug_stats(unsigned long long* out8) {
 #endif
 
 #ifdef OCC_DBG_TIME
-extern "C" int occ_debug_time(unsigned long long* out32) {
-    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(occ::g_dbg_time), 32 * sizeof(unsigned long long)) != hipSuccess) return 2;
-    unsigned long long z[32] = {0};
+extern "C" int occ_debug_time(unsigned long long* out112) {
+    if (hipMemcpyFromSymbol(out112, HIP_SYMBOL(occ::g_dbg_time), 112 * sizeof(unsigned long long)) != hipSuccess) return 2;
+    unsigned long long z[112] = {0};
     z[16] = ~0ull;
+    for (int i = 96; i < 104; ++i) z[i] = ~0ull;
     return hipMemcpyToSymbol(HIP_SYMBOL(occ::g_dbg_time), z, sizeof(z)) == hipSuccess ? 0 : 2;
 }
 #endif

@@ -55,12 +55,24 @@ constexpr int kSweepU = 4;     // 64-entry rows of the log per sweep group; two 
                                // 16-byte double rows were measured slower: they push the kernel into spilling)
 constexpr int kListCap = 8;    // boundary-bucket entries per pixel that the owner lane resolves itself
 constexpr int kCopies = 4;     // accumulator copies (staged face & 3)
-constexpr int kAccStride = 73; // float4 slots per copy: pixel slot = 9 * py + px, copy stride = 9 mod 16 -> bank-spread
+constexpr int kAccStride = 65; // accumulator slots per copy: one per pixel, +1 so that the copies of a pixel differ mod 16 (acc_slot)
 
 struct WaveLog {
     float4* __restrict__ pay;  // (1 - p, g_el, g_az, -)
     uint2* __restrict__ kt;    // (order-preserving depth key, pixel of the tile 0..63)
 };
+
+// Accumulator slot of pixel pix (= 8 py + px) in copy cpy.  A 16-byte LDS access is served 16 lanes at a time, one per
+// residue of the slot index mod 16: the column is rotated by 3 every second row and the copy stride is 1 mod 16, so that
+// the rows of a face's footprint and the four copies of one pixel (four faces evaluated side by side) land on
+// different residues.
+__device__ __forceinline__ int acc_slot(int cpy, int pix) {
+    return cpy * kAccStride + (pix & 56) + ((pix + 3 * (pix >> 4)) & 7);
+}
+// Largest stored key of a (copy, pixel) as an upper bound in 16 bits: the key's high half + 1.  Only ever used as a bound
+// from above (a looser bound prunes a little less, never wrongly); 0 = nothing stored.
+__device__ __forceinline__ uint16_t akm_enc(uint32_t key) { return (uint16_t)min(0xFFFFu, (key >> 16) + 1u); }
+__device__ __forceinline__ uint32_t akm_dec(uint32_t v) { return v >= 0xFFFFu ? 0xFFFFFFFFu : v << 16; }
 
 __device__ __forceinline__ float unzkey(uint32_t k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
@@ -70,21 +82,30 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {  // set bits of
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-#ifdef OCC_DBG_TIME  // diagnostic build only: shader cycles per phase of the raster kernel, summed over waves
-// [0..15] cycles per phase; [16] earliest wave start, [17] latest wave end, [18] sum of wave ends, [19] waves,
-// [20] sum / [21] count / [22] max of item times with an overflowing pixel, [23] sum / [24] count of the others
-// ([16..24] in s_memrealtime ticks, 100 MHz)
-__device__ unsigned long long g_dbg_time[32];
+#ifdef OCC_DBG_TIME  // diagnostic build only: where the wave-time of the raster kernel goes
+// [0..15] shader cycles per phase, summed over waves.  In s_memrealtime ticks (100 MHz): [16] earliest wave start,
+// [17] latest wave end, [18] sum of wave ends, [19] waves, [20] sum / [21] count / [22] max of the item times with an
+// overflowing pixel, [23] sum / [24] count of the others, [25] sum / [26] max of (last item end -> exit), [27] waves
+// that started > 50 us after the first, [32 + b] waves ending in the b-th 100 us after the first start, [64 + b] sum
+// of their last item's time, [96 + x] earliest wave start on XCD x, [104 + x] latest wave end there.
+// The end time is taken BEFORE the flush (3072 waves x ~30 atomics on a few lines take ~0.5 ms by themselves), and the
+// flush of the early finishers still slows the queue atomics of the others: tails read from this build are upper bounds.
+__device__ unsigned long long g_dbg_time[112];
 #define OCC_T_DECL unsigned long long t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long t_last = __builtin_amdgcn_s_memtime(); \
-    const unsigned long long t_w0 = __builtin_amdgcn_s_memrealtime(); unsigned long long t_item = t_w0, t_os = 0, t_on = 0, t_om = 0, t_ns = 0, t_nn = 0
-#define OCC_T_ITEM(heavy) do { const unsigned long long t_n = __builtin_amdgcn_s_memrealtime(), d_ = t_n - t_item; t_item = t_n; \
+    const unsigned long long t_w0 = __builtin_amdgcn_s_memrealtime(); unsigned long long t_item = t_w0, t_os = 0, t_on = 0, t_om = 0, t_ns = 0, t_nn = 0, t_lastd = 0
+#define OCC_T_ITEM(heavy) do { const unsigned long long t_n = __builtin_amdgcn_s_memrealtime(), d_ = t_n - t_item; t_item = t_n; t_lastd = d_; \
         if (heavy) { t_os += d_; t_on += 1; t_om = d_ > t_om ? d_ : t_om; } else { t_ns += d_; t_nn += 1; } } while (0)
 #define OCC_T(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
-#define OCC_T_FLUSH do { if (lane == 0) { for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_dbg_time[i_], t_acc[i_]); \
-        const unsigned long long t_e = __builtin_amdgcn_s_memrealtime(); \
+#define OCC_T_FLUSH do { if (lane == 0) { const unsigned long long t_e = __builtin_amdgcn_s_memrealtime(); \
+        for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_dbg_time[i_], t_acc[i_]); \
         atomicMin(&g_dbg_time[16], t_w0); atomicMax(&g_dbg_time[17], t_e); atomicAdd(&g_dbg_time[18], t_e); atomicAdd(&g_dbg_time[19], 1ull); \
         atomicAdd(&g_dbg_time[20], t_os); atomicAdd(&g_dbg_time[21], t_on); atomicMax(&g_dbg_time[22], t_om); \
-        atomicAdd(&g_dbg_time[23], t_ns); atomicAdd(&g_dbg_time[24], t_nn); } } while (0)
+        atomicAdd(&g_dbg_time[23], t_ns); atomicAdd(&g_dbg_time[24], t_nn); atomicAdd(&g_dbg_time[25], t_e - t_item); atomicMax(&g_dbg_time[26], t_e - t_item); \
+        const unsigned long long first_ = *(volatile unsigned long long*)&g_dbg_time[16], rel_ = t_e - first_; \
+        const int b_ = (int)(rel_ / 10000ull > 31ull ? 31ull : rel_ / 10000ull); \
+        atomicAdd(&g_dbg_time[32 + b_], 1ull); atomicAdd(&g_dbg_time[64 + b_], t_lastd); \
+        if (t_w0 - first_ > 5000ull) atomicAdd(&g_dbg_time[27], 1ull); \
+        atomicMin(&g_dbg_time[96 + my_xcc], t_w0); atomicMax(&g_dbg_time[104 + my_xcc], t_e); } } while (0)
 #else
 #define OCC_T_DECL do { } while (0)
 #define OCC_T(i) do { } while (0)
@@ -124,8 +145,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
     __shared__ int s_hit[2 * kStg2];               // record index of every staged face
     __shared__ uint2 s_box[2 * kStg2];             // its pixel bbox (xl | yl << 16, xh | yh << 16), then (pre, geometry)
     __shared__ float4 s_acc[kCopies * kAccStride]; // (prod (1 - p_k), sum g_el, sum g_az, count) per copy and pixel
-    __shared__ uint32_t s_akm[kCopies * kAccStride];  // largest stored key per copy and pixel
-    __shared__ uint32_t s_bnd[64];                 // key bound of every pixel
+    __shared__ uint16_t s_akm[kCopies * kAccStride];  // bound on the largest stored key per copy and pixel (akm_enc)
     __shared__ unsigned long long s_hard[64];
 
     WaveLog lg;
@@ -141,7 +161,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
     const int mq = xcd_slots(P.sc.n_env), MP = 8 * mq;
     const int my_xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;  // steers which queue is drained first only
     int qround = 0;
-    const int myslot = 9 * (lane >> 3) + (lane & 7);  // accumulator slot of the pixel this lane owns
+    const int myslot = acc_slot(0, lane);  // accumulator slot (copy 0) of the pixel this lane owns
     OCC_T_DECL;
 
     for (;;) {
@@ -196,14 +216,13 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #pragma unroll
         for (int cpy = 0; cpy < kCopies; ++cpy) {
             s_acc[cpy * kAccStride + myslot] = make_float4(1.f, 0.f, 0.f, 0.f);
-            s_akm[cpy * kAccStride + myslot] = 0u;
+            s_akm[cpy * kAccStride + myslot] = 0;
         }
-        s_bnd[lane] = 0xFFFFFFFFu;
         s_hard[lane] = ~0ull;
         OCC_T(1);  // item decode + state init
         int nlog = 0;               // entries in the wave's log (wave-uniform)
         bool lim_on = false;        // this lane's pixel already holds >= K candidates
-        uint32_t bnd = 0xFFFFFFFFu; // key bound of this lane's pixel (copy of s_bnd[lane])
+        uint32_t bnd = 0xFFFFFFFFu; // key bound of this lane's pixel (pair lanes read it across lanes)
         uint32_t thrB = 0xFFFFFFFFu;      // tile-wide skip key (wave-uniform)
         uint32_t kmin_tile = 0xFFFFFFFFu; // smallest depth key any candidate of this tile can have (chunk boxes)
         uint32_t kmx_lane = 0u;           // largest key this lane has appended to the log (selection window)
@@ -217,11 +236,10 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
         };
         // this lane's pixel: candidates held and their largest key (four copies folded)
         auto own_count = [&]() {
-            return (int)(s_acc[myslot].w + s_acc[kAccStride + myslot].w + s_acc[2 * kAccStride + myslot].w +
-                         s_acc[3 * kAccStride + myslot].w);
+            return (int)(s_acc[myslot].w + s_acc[1 * kAccStride + myslot].w + s_acc[2 * kAccStride + myslot].w + s_acc[3 * kAccStride + myslot].w);
         };
         auto own_kmax = [&]() {
-            return max(max(s_akm[myslot], s_akm[kAccStride + myslot]), max(s_akm[2 * kAccStride + myslot], s_akm[3 * kAccStride + myslot]));
+            return akm_dec(max(max((uint32_t)s_akm[myslot], (uint32_t)s_akm[1 * kAccStride + myslot]), max((uint32_t)s_akm[2 * kAccStride + myslot], (uint32_t)s_akm[3 * kAccStride + myslot])));
         };
 
         // ---- exact top-K over the log for every pixel holding more than K entries ---------------------------
@@ -444,11 +462,11 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 if (ovf) {  // the selected sums become the pixel's accumulated state (copy 0; the others empty)
                     const float4 a2 = s_acc2[lane];
                     s_acc[myslot] = make_float4(__builtin_amdgcn_exp2f(a2.x), a2.y, a2.z, a2.w);
-                    s_akm[myslot] = s_kmax2[lane];
+                    s_akm[myslot] = akm_enc(s_kmax2[lane]);
 #pragma unroll
                     for (int cpy = 1; cpy < kCopies; ++cpy) {
                         s_acc[cpy * kAccStride + myslot] = make_float4(1.f, 0.f, 0.f, 0.f);
-                        s_akm[cpy * kAccStride + myslot] = 0u;
+                        s_akm[cpy * kAccStride + myslot] = 0;
                     }
                 }
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the rewritten log is in place before it grows again
@@ -611,7 +629,6 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     if (dense && own_count() >= K) {
                         lim_on = true;
                         bnd = min(bnd, own_kmax());
-                        s_bnd[lane] = bnd;
                     }
                     // the histograms lived on top of the records and the pair map: put both back
                     stage_records();
@@ -681,7 +698,10 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     }
                     if (SOFT) {
                         const uint32_t key = zkey(c1.z);
-                        const bool acc = live && c1.cand && (!dense || key < s_bnd[pix]);
+                        // dense objects: the pixel's bound sits in its owner lane (bnd; only changes between batches)
+                        uint32_t pbnd = 0xFFFFFFFFu;
+                        if (dense) pbnd = (uint32_t)__shfl((int)bnd, pix, 64);
+                        const bool acc = live && c1.cand && (!dense || key < pbnd);
                         const unsigned long long m = __ballot(acc);
                         if (m) {
 #ifndef OCC_DBG2_NO_LOG  // timing experiment only
@@ -696,7 +716,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                             // accumulate: plain read-modify-write in sub-passes of four consecutive staged faces
                             const int f_first = __builtin_amdgcn_readfirstlane(f);
                             const int f_last = __builtin_amdgcn_readlane(f, nlive - 1);
-                            const int slot = (f & 3) * kAccStride + 9 * (pix >> 3) + (pix & 7);
+                            const int slot = acc_slot(f & 3, pix);
                             const int grp = (f - f_first) >> 2;
                             const int nsub = ((f_last - f_first) >> 2) + 1;
                             for (int sp = 0; sp < nsub; ++sp) {
@@ -709,7 +729,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                                     }
                                     a.w += 1.0f;
                                     s_acc[slot] = a;
-                                    if (dense) s_akm[slot] = max(s_akm[slot], key);
+                                    if (dense) s_akm[slot] = max(s_akm[slot], akm_enc(key));
                                 }
                             }
                             if (acc) kmx_lane = max(kmx_lane, key);
@@ -731,7 +751,6 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 if (dense && !lim_on && own_count() >= K) {
                     lim_on = true;
                     bnd = min(bnd, own_kmax());
-                    s_bnd[lane] = bnd;
                 }
                 bound = bnd;
             }
@@ -784,8 +803,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 sge = a2.y;
                 sga = a2.z;
             } else {  // fold the four copies in a fixed order
-                const float4 a0 = s_acc[myslot], a1 = s_acc[kAccStride + myslot], a2 = s_acc[2 * kAccStride + myslot],
-                             a3 = s_acc[3 * kAccStride + myslot];
+                const float4 a0 = s_acc[myslot], a1 = s_acc[1 * kAccStride + myslot], a2 = s_acc[2 * kAccStride + myslot], a3 = s_acc[3 * kAccStride + myslot];
                 prod = (a0.x * a1.x) * (a2.x * a3.x);
                 sge = (a0.y + a1.y) + (a2.y + a3.y);
                 sga = (a0.z + a1.z) + (a2.z + a3.z);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# one-box interleaved A/B of two configurations of the raster path (env toggles or OCC_HIP_LIB builds)
+# one-box interleaved A/B of configurations of the raster path (env toggles or OCC_HIP_LIB builds)
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 run() {
   name=$1; shift
@@ -10,6 +10,6 @@ for l in sys.stdin:
         j = json.loads(l); print('$name', 'raster %.3f ms' % j['roofline']['avg_launch_ms'], 'step %.3f ms' % j['ms_per_step'], '%.0f steps/s' % j['value'])"
 }
 for r in 1 2 3; do
-  run rect OCC_ORDER=0
-  run cost OCC_ORDER=1
+  run before OCC_HIP_LIB=$PWD/build/dbg2/libocc_akm32.so
+  run after X=1
 done

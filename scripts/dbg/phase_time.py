@@ -18,7 +18,7 @@ for mesh, img in [("synthetic", 128), ("mixed", 128), ("teapot", 128)]:
     a = case["actions"].cuda().requires_grad_(True)
     eng.step(a)
     torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * 32)()
+    buf = (ctypes.c_ulonglong * 112)()
     lib.occ_debug_time(buf)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
@@ -35,4 +35,7 @@ for mesh, img in [("synthetic", 128), ("mixed", 128), ("teapot", 128)]:
           % (nw, span, (tsum / nw - t0) / 100.0, 100.0 * (1.0 - (tsum / nw - t0) / max(t1 - t0, 1))),
           "items with selection: %d, mean %.0f us, max %.0f us; others: %d, mean %.1f us"
           % (buf[21], buf[20] / max(buf[21], 1) / 100.0, buf[22] / 100.0, buf[24], buf[23] / max(buf[24], 1) / 100.0), flush=True)
+    print("   wave ends per 100 us (count:mean last item us):", " ".join("[%d]%d:%.0f" % (b, buf[32 + b], buf[64 + b] / max(buf[32 + b], 1) / 100.0) for b in range(32) if buf[32 + b]), flush=True)
+    print("   last item end -> exit: mean %.1f us, max %.1f us; waves that started > 50 us late: %d" % (buf[25] / nw / 100.0, buf[26] / 100.0, buf[27]))
+    print("   per XCD (first start, last end) us after the earliest start:", " ".join("(%.0f, %.0f)" % ((buf[96 + x] - t0) / 100.0, (buf[104 + x] - t0) / 100.0) for x in range(8)), flush=True)
     del eng
