@@ -49,7 +49,7 @@ extern "C" {
 #define OCC_ERR_LAUNCH 2 /* hipLaunch failed (hipGetLastError != success) */
 
 /* per-env status bits written by the kernels (0 = fine) */
-#define OCC_STATUS_LIST_OVERFLOW 1 /* reserved (lists are compacted exactly, never dropped) */
+#define OCC_STATUS_LIST_OVERFLOW 1 /* internal error: a pixel of a tile whose cost class rules it out held more than K candidates */
 #define OCC_STATUS_REC_OVERFLOW 2  /* more visible (clipped) faces than record capacity */
 
 /* layout constants shared with the host */
@@ -138,7 +138,7 @@ typedef struct OccWorkspace {
      *   [0..8] first item of every XCD queue and the total, [16 + 32 q + c] tiles of cost class c in queue q,
      *   [512 + 32 (env*3+obj) + c] where the object's class-c tiles start inside the class,
      *   then (n_env,3,T) per tile: rank inside the object's class << 5 | class   (T = (S/8)^2 tiles per image),
-     *   then (n_env*3*T) items (env*3+obj, tile index inside the object's rect), 8 B each.
+     *   then (n_env*3*T) items (env*3+obj, tile index inside the object's rect | class << 24), 8 B each.
      * occ_render zeroes the first 512 words. */
     uint32_t* order;
 } OccWorkspace;

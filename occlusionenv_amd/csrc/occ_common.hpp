@@ -33,6 +33,14 @@ __device__ __forceinline__ int ord_class(uint32_t c) {
     return min(kOrdClasses - 1, 1 + 2 * fl + half);
 }
 
+// faces that touch a tile of class cls: strictly fewer than this
+__device__ __forceinline__ uint32_t ord_class_bound(int cls) {
+    if (cls <= 0) return 1u;
+    if (cls >= kOrdClasses - 1) return 0xFFFFFFFFu;
+    const int fl = (cls - 1) >> 1, half = (cls - 1) & 1;
+    return fl == 0 ? 2u : (half ? 2u << fl : 3u << (fl - 1));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(64) void occ_order_kernel(const int* __restrict__ o
     for (int local = lane; local < ntile; local += 64) {
         const uint32_t w = tord[local];
         const uint32_t pos = s_base[w & 31u] + (w >> 5);
-        if (pos < cap) items[pos] = make_uint2((uint32_t)eo, (uint32_t)local);
+        if (pos < cap) items[pos] = make_uint2((uint32_t)eo, (uint32_t)local | (w & 31u) << 24);  // tile | cost class
     }
 }
 

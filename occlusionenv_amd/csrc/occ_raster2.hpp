@@ -43,7 +43,7 @@
 #define OCC_LOG_CAP 12288  // log entries per wave; must hold a compacted log (64 * OCC_MAX_K) plus the pairs of one batch
 #endif
 static_assert(OCC_LOG_CAP >= 64 * OCC_MAX_K + 2048 + 64, "OCC_LOG_CAP too small");
-#define OCC_LOG_BYTES ((size_t)OCC_LOG_CAP * 24)  // 16 B payload + 8 B (key, pixel)
+#define OCC_LOG_BYTES ((size_t)OCC_LOG_CAP * 20)  // 12 B payload + 8 B (key, pixel)
 
 constexpr int kT2 = 8;         // tile side in pixels (== OCC_TILE)
 constexpr int kStg2 = 32;      // faces staged per batch (LDS budget: 12 waves per CU need <= 13.3 KB each)
@@ -57,8 +57,11 @@ constexpr int kListCap = 8;    // boundary-bucket entries per pixel that the own
 constexpr int kCopies = 4;     // accumulator copies (staged face & 3)
 constexpr int kAccStride = 65; // accumulator slots per copy: one per pixel, +1 so that the copies of a pixel differ mod 16 (acc_slot)
 
+struct LogPay {  // 12 bytes, moved with one dwordx3 access
+    float q, ge, ga;  // 1 - p, g_el, g_az
+};
 struct WaveLog {
-    float4* __restrict__ pay;  // (1 - p, g_el, g_az, -)
+    LogPay* __restrict__ pay;
     uint2* __restrict__ kt;    // (order-preserving depth key, pixel of the tile 0..63)
 };
 
@@ -151,8 +154,8 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
     WaveLog lg;
     {
         char* base = reinterpret_cast<char*>(P.ws.lists) + (size_t)blockIdx.x * OCC_LOG_BYTES;
-        lg.pay = reinterpret_cast<float4*>(base);
-        lg.kt = reinterpret_cast<uint2*>(base + (size_t)OCC_LOG_CAP * 16);
+        lg.pay = reinterpret_cast<LogPay*>(base);
+        lg.kt = reinterpret_cast<uint2*>(base + (size_t)OCC_LOG_CAP * 12);
     }
     ciptr offs = as_const(P.ws.offsets);
     ciptr ord = as_const(reinterpret_cast<const int*>(P.ws.order));  // null: rect order through offs
@@ -182,10 +185,15 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
         if (item < 0) break;
         OCC_T(0);  // dequeue
         int eo, local;
+        // A tile that fewer than K + 1 faces touch cannot hold a pixel with more than K candidates: its candidates
+        // need no log (nothing will ever be selected from it).  The item's cost class bounds the faces from above.
+        bool nolog = false;
         if (ord) {  // cost order (occ_order_kernel): the item list names the tile
             const uint2 it = ord_items[item];
             eo = __builtin_amdgcn_readfirstlane((int)it.x);
-            local = __builtin_amdgcn_readfirstlane((int)it.y);
+            const int w = __builtin_amdgcn_readfirstlane((int)it.y);
+            local = w & 0xFFFFFF;
+            nolog = ord_class_bound(w >> 24) <= (uint32_t)K + 1u;
         } else {    // rect order: find the (env, object) whose item range holds this one
             int lo = 0, hi = MP;
             while (hi - lo > 1) {
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             int wr = 0;
             auto settle = [&](const int e0, const uint2 (&kt)[kSweepU]) __attribute__((always_inline)) {
                 uint32_t keepm = 0u, readdm = 0u;  // per-row decisions of this lane, bit u
-                float4 pv[kSweepU];
+                LogPay pv[kSweepU];
 #pragma unroll
                 for (int u = 0; u < kSweepU; ++u) {  // decisions in log order (ties are served first come)
                     if (kt[u].y < 64u) {
@@ -378,17 +386,17 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #pragma unroll
                 for (int u = 0; u < kSweepU; ++u) {
                     const int e = e0 + u * 64 + lane;
-                    pv[u] = (((readdm | (compact ? keepm : 0u)) >> u) & 1u) ? lg.pay[e] : make_float4(1.f, 0.f, 0.f, 0.f);
+                    pv[u] = (((readdm | (compact ? keepm : 0u)) >> u) & 1u) ? lg.pay[e] : LogPay{1.f, 0.f, 0.f};
                 }
 #pragma unroll
                 for (int u = 0; u < kSweepU; ++u) {
                     if ((readdm >> u) & 1u) {
                         const uint32_t t = kt[u].y & 63u;
                         // product of the kept (1 - p_k) in the log domain: exp2(sum log2); log2(0) = -inf -> 0
-                        atomicAdd(&s_acc2[t].x, __builtin_amdgcn_logf(pv[u].x));
+                        atomicAdd(&s_acc2[t].x, __builtin_amdgcn_logf(pv[u].q));
                         if (GRAD) {
-                            atomicAdd(&s_acc2[t].y, pv[u].y);
-                            atomicAdd(&s_acc2[t].z, pv[u].z);
+                            atomicAdd(&s_acc2[t].y, pv[u].ge);
+                            atomicAdd(&s_acc2[t].z, pv[u].ga);
                         }
                         if (compact) {  // count and largest key only matter when the loop goes on
                             atomicAdd(&s_acc2[t].w, 1.0f);
@@ -441,17 +449,17 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                         rank += (be[jj].x < be[i].x || (be[jj].x == be[i].x && be[jj].y < be[i].y)) ? 1 : 0;
                     if (i < nb && rank < need) takem |= 1u << i;
                 }
-                float4 pv[kListCap];
+                LogPay pv[kListCap];
 #pragma unroll
-                for (int i = 0; i < kListCap; ++i) pv[i] = ((takem >> i) & 1u) ? lg.pay[be[i].y] : make_float4(1.f, 0.f, 0.f, 0.f);
+                for (int i = 0; i < kListCap; ++i) pv[i] = ((takem >> i) & 1u) ? lg.pay[be[i].y] : LogPay{1.f, 0.f, 0.f};
                 float4 a2 = s_acc2[lane];
                 float sl = a2.x, se = a2.y, sa = a2.z;
 #pragma unroll
                 for (int i = 0; i < kListCap; ++i) {
                     if ((takem >> i) & 1u) {
-                        sl += __builtin_amdgcn_logf(pv[i].x);
-                        se += pv[i].y;
-                        sa += pv[i].z;
+                        sl += __builtin_amdgcn_logf(pv[i].q);
+                        se += pv[i].ge;
+                        sa += pv[i].ga;
                     }
                 }
                 s_acc2[lane] = make_float4(sl, se, sa, a2.w);
@@ -705,13 +713,13 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                         const unsigned long long m = __ballot(acc);
                         if (m) {
 #ifndef OCC_DBG2_NO_LOG  // timing experiment only
-                            if (acc) {
+                            if (acc && !nolog) {
                                 const int e = nlog + lane_rank(m);
                                 lg.kt[e] = make_uint2(key, (uint32_t)pix);
-                                lg.pay[e] = make_float4(c1.q, c1.ge, c1.ga, 0.f);
+                                lg.pay[e] = LogPay{c1.q, c1.ge, c1.ga};
                             }
 #endif
-                            nlog += __popcll(m);
+                            if (!nolog) nlog += __popcll(m);
 #ifndef OCC_DBG2_NO_ATOM  // timing experiment only
                             // accumulate: plain read-modify-write in sub-passes of four consecutive staged faces
                             const int f_first = __builtin_amdgcn_readfirstlane(f);
@@ -792,7 +800,13 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #endif
             bool selected = false;
 #ifndef OCC_DBG2_NO_SEL  // timing experiment only
-            if (__ballot(ovf)) selected = select_topk(false);  // more than K candidates: keep the K nearest in z, A.4
+            if (__ballot(ovf)) {
+                if (nolog) {  // cannot happen (the class bound counts every face that can reach the tile): say so loudly
+                    if (lane == 0) atomicOr(&P.ws.status[eo / 3], OCC_STATUS_LIST_OVERFLOW);
+                } else {
+                    selected = select_topk(false);  // more than K candidates: keep the K nearest in z, A.4
+                }
+            }
 #endif
             OCC_T(8);  // final selection
             OCC_T_ITEM(__ballot(ovf) != 0ull);

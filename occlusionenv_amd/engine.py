@@ -237,7 +237,7 @@ class OcclusionEngine:
             self.status.zero_()
             raise nat.NativeError(
                 f"kernel status {st} for envs {bad}: "
-                f"{'a pixel exceeded OCC_LIST_CAP soft candidates; ' if st & nat.STATUS_LIST_OVERFLOW else ''}"
+                f"{'internal error: a tile classed as overflow-free held a pixel with more than K candidates; ' if st & nat.STATUS_LIST_OVERFLOW else ''}"
                 f"{'face-record capacity exceeded' if st & nat.STATUS_REC_OVERFLOW else ''}")
 
     # ---- launches -------------------------------------------------------------------------

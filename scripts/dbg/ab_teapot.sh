@@ -1,15 +1,15 @@
 #!/bin/bash
-# one-box interleaved A/B of configurations of the raster path (env toggles or OCC_HIP_LIB builds)
+# A/B on BASELINE config 2 (teapot, 256 envs, 128 px): previous build vs current
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 run() {
   name=$1; shift
-  env "$@" timeout -k 10 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pool-models 64 2>/dev/null | python -c "
+  env "$@" timeout -k 10 200 python bench.py --workload teapot --envs 256 --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         j = json.loads(l); print('$name', 'raster %.3f ms' % j['roofline']['avg_launch_ms'], 'step %.3f ms' % j['ms_per_step'], '%.0f steps/s' % j['value'])"
 }
-for r in 1 2 3; do
+for r in 1 2; do
   run before OCC_HIP_LIB=$PWD/build/dbg2/libocc_prev.so
   run after X=1
 done

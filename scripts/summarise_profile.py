@@ -11,7 +11,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, "profiles")
 os.makedirs(prof, exist_ok=True)
 
-stats = glob.glob(os.path.join(out, "trace", "*", "*kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(out, "trace", "*", "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)  # newest run
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
     with open(os.path.join(prof, f"{rnd}_kernel_stats.csv"), "w") as fh:
@@ -22,7 +22,7 @@ if stats:
 
 
 def counters(sub):
-    f = glob.glob(os.path.join(out, sub, "*", "*counter_collection.csv"))
+    f = sorted(glob.glob(os.path.join(out, sub, "*", "*counter_collection.csv")), key=os.path.getmtime, reverse=True)  # newest run
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     if f:
         for r in csv.DictReader(open(f[0])):
