@@ -130,6 +130,9 @@ class SimpleVecEnv(VecEnv):
         self._rs_state = np.zeros(reserve, dtype=np.int32)
         self._pending = None                # (report handle, obs, out, infos) of the last step, not yet read
         self._late = []                     # slots refilled AFTER the pairing of the step whose report is pending
+        self._taken_host, self._taken_flip = None, 0  # pinned staging of the slot indices (double-buffered)
+        self._half = None                   # (report handle, infos, taken slots, their envs) of a report read by the
+        #                                     fast half of _drain whose per-env bookkeeping has not run yet
         self._fin_recent = 0.0              # decaying maximum of the number of envs that finished in one step
         self._warm = False
         # optional torch.cuda.Event: recorded by an asynchronous consumer of the last step's ``obs`` (another stream)
@@ -187,12 +190,19 @@ class SimpleVecEnv(VecEnv):
         eng.set_reserve_state(self._rs_state, np.zeros(R, dtype=np.int32))
         self._warm = True
 
-    def _drain(self, defer_refill=False):
+    def _drain(self, defer_refill=False, finish=True):
         """Read the auto-reset report of the last step (the ONE host sync per batched step, taken as late as
         possible: at the start of the next step or when infos are first read) and do the host's share: scene
         bookkeeping of the envs that were reset, terminal observations, new candidate scenes for the slots the
         device emptied, and the synchronous fallback if the reserve ran dry.  With ``defer_refill`` the EMPTY
-        slots are returned instead of refilled (step_wait refills them after it has launched the next step)."""
+        slots are returned instead of refilled (step_wait refills them after it has launched the next step).
+
+        The GPU is idle from the moment the report arrives until the next step's first launch, so the work is split:
+        this half does only what that launch depends on (status, the host copy of the scene mesh ids that sizes the
+        record arrays, the fallback reset, the slot states); with ``finish=False`` the per-env bookkeeping
+        (terminal observations, scenes, stored renders) is left to ``_drain_finish``, which step_wait calls right
+        after the launch."""
+        self._drain_finish()  # bookkeeping left over from an earlier fast drain
         if self._pending is None:
             return []
         pend, obs, out, infos = self._pending
@@ -207,16 +217,13 @@ class SimpleVecEnv(VecEnv):
         assign = rep[N + R:N + 2 * R]
         self._fin_recent = max(0.9 * self._fin_recent, float(np.count_nonzero(rep[:N])))
         taken = np.nonzero(assign >= 0)[0]
-        for r in taken.tolist():
-            i = int(assign[r])
-            # save final observation where user can get it, then reset (SubProcVecEnv.py:211-214)
-            infos.set(i, "terminal_observation", pend["term"][r:r + 1])
-            self.envs[i]._scene = self._rs_scene[r]
-            eng.note_commit(i, r)
-            self.envs[i].image = eng._res_fs[r:r + 1].clone()  # the slot's stored render (it will be overwritten)
+        took = assign[taken].astype(np.int64)  # env that took slot taken[j]
+        eng.note_commits(took, taken)
+        self._half = (pend, infos, taken.tolist(), took.tolist())
         if rep[N + 2 * R + 1]:  # reserve exhausted: synchronous batched reset for the rest
+            self._drain_finish()
             done_envs = set(np.nonzero(rep[:N])[0].tolist())
-            left = sorted(done_envs - set(int(assign[r]) for r in taken.tolist()))
+            left = sorted(done_envs - set(took.tolist()))
             term = obs[left].clone()
             for j, i in enumerate(left):
                 infos.set(i, "terminal_observation", term[j:j + 1])
@@ -228,10 +235,36 @@ class SimpleVecEnv(VecEnv):
         self._late = []
         self._rs_state = state
         empty = np.nonzero(state == nat.RS_EMPTY)[0].tolist()
+        if finish:
+            self._drain_finish()
         if defer_refill:
             return empty
         self._refill_reserve(empty)
         return []
+
+    def _drain_finish(self):
+        """Second half of _drain: what the envs that took a reserve slot get from it.  Must run before the slots are
+        refilled (``_rs_scene``) and before the launch after next (which may overwrite their stored renders)."""
+        if self._half is None:
+            return
+        pend, infos, taken, took = self._half
+        self._half = None
+        if not taken:
+            return
+        eng = self.engine
+        # the slots' stored renders (they will be overwritten): ONE gather for all of them
+        # (indices through pinned memory: a pageable upload would make the host wait for the step just launched)
+        if self._taken_host is None:
+            self._taken_host = [torch.zeros(eng.R, dtype=torch.int64).pin_memory() for _ in range(2)]
+        self._taken_flip ^= 1
+        th = self._taken_host[self._taken_flip]
+        th.numpy()[:len(taken)] = taken
+        images = eng._res_fs[th[:len(taken)].to(eng.device, non_blocking=True)]
+        for j, (r, i) in enumerate(zip(taken, took)):
+            # save final observation where user can get it, then reset (SubProcVecEnv.py:211-214)
+            infos.set(i, "terminal_observation", pend["term"][r:r + 1])
+            self.envs[i]._scene = self._rs_scene[r]
+            self.envs[i].image = images[j:j + 1]
 
     def step_wait(self):
         eng = self.engine
@@ -248,7 +281,8 @@ class SimpleVecEnv(VecEnv):
             # and its launch arguments are built, right before its first kernel launch
             empty = []
             obs, rewards, dones, full_state, loss, out = eng.step(
-                actions, with_reserve=True, pre_launch=lambda: empty.extend(self._drain(defer_refill=True)))
+                actions, with_reserve=True, pre_launch=lambda: empty.extend(self._drain(defer_refill=True, finish=False)))
+            self._drain_finish()  # the rest of the previous step's report, now that this step is on its way
             # finished envs are reset ON THE DEVICE from the reserve (pairing + commit); the host reads the
             # report later (_drain).  NB out["obs_all"][:N] IS obs: the commit writes the reset observation in place
             pos = eng.camera_position.clone()

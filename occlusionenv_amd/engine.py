@@ -173,6 +173,11 @@ class OcclusionEngine:
         """The device installed reserve ``slot``'s scene in ``env_id`` (occ_auto_reset): keep the host copy current."""
         self._mesh_host[env_id] = self._mesh_host[self.N + slot]
 
+    def note_commits(self, env_ids, slots) -> None:
+        """``note_commit`` for a batch (index arrays; an env takes at most one slot per step)."""
+        if len(env_ids):
+            self._mesh_host[np.asarray(env_ids)] = self._mesh_host[self.N + np.asarray(slots)]
+
     def _ensure_workspace(self, need_records: Optional[int] = None) -> nat.OccWorkspace:
         """Fixed-size scratch (planes, K-buffers, ...) once; the record arrays hold ``rec_total`` records in a
         variable layout (every object gets room for ITS mesh) and grow geometrically when a launch needs more."""

@@ -12,17 +12,6 @@ export TMPDIR=/tmp
 run() {  # tag, bench args
   tag=$1; shift
   (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$tag" -- python "$ROOTD/bench.py" --no-cpu-baseline "$@" > "$OUT/$tag.log" 2>&1)
-  python - "$OUT/$tag" "$tag" "$R" <<'PY'
-import csv, glob, json, os, sys
-d, tag, rnd = sys.argv[1:4]
-f = glob.glob(os.path.join(d, "*", "*kernel_stats.csv"))
-rows = list(csv.DictReader(open(f[0])))[:8] if f else []
-log = [l for l in open(d + ".log") if l.startswith("{")]
-bench = json.loads(log[-1]) if log else None
-json.dump({"config": tag, "bench": bench, "kernels": [{k: r[k] for k in ("Name", "Calls", "AverageNs", "Percentage")} for r in rows]},
-          open(os.path.join("profiles", f"{rnd}_{tag}.json"), "w"), indent=1)
-print(tag, bench and ("%.0f steps/s, %.2f ms/step" % (bench["value"], bench["ms_per_step"])))
-PY
 }
 run config2_teapot256 --workload teapot --envs 256 --img 128 --steps 40 --warmup 5
 run config5size_2048x256 --workload shapenet5k --envs 2048 --img 256 --steps 6 --warmup 2
@@ -30,5 +19,4 @@ run mixed1024 --workload mixed --envs 1024 --img 128 --steps 20 --warmup 3
 # N>1 rehearsal: two ranks (gloo) sharing the single GPU: exercises sharding, the side-stream record exchange, the gather
 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
     bench.py --gpus 2 --dist-backend gloo --envs 512 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/n2_gloo.log" 2>&1
-grep '^{' "$OUT/n2_gloo.log" | tail -1 > profiles/${R}_n2_gloo_rehearsal.json
-cut -c1-300 profiles/${R}_n2_gloo_rehearsal.json
+python scripts/summarise_configs.py "$OUT" "$R"

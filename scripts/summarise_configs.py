@@ -1,0 +1,22 @@
+"""profiles/<round>_<config>.json from the rocprofv3 output of scripts/profile_configs.sh (gpurun_out/<round>_cfg):
+   python scripts/summarise_configs.py gpurun_out/r02_cfg r02
+Runs on the GPU box at the end of profile_configs.sh and again locally (profiles/ written on the box does not travel back)."""
+import csv, glob, json, os, sys
+
+out, rnd = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for logf in sorted(glob.glob(os.path.join(out, "*.log"))):
+    tag = os.path.basename(logf)[:-4]
+    lines = [l for l in open(logf) if l.startswith("{")]
+    if not lines:
+        continue
+    bench = json.loads(lines[-1])
+    if tag == "n2_gloo":
+        json.dump(bench, open(os.path.join(root, "profiles", f"{rnd}_n2_gloo_rehearsal.json"), "w"))
+        print(tag, "%.0f steps/s, %.2f ms/step" % (bench["value"], bench["ms_per_step"]))
+        continue
+    f = sorted(glob.glob(os.path.join(out, tag, "*", "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)  # newest run
+    rows = list(csv.DictReader(open(f[0])))[:8] if f else []
+    json.dump({"config": tag, "bench": bench, "kernels": [{k: r[k] for k in ("Name", "Calls", "AverageNs", "Percentage")} for r in rows]},
+              open(os.path.join(root, "profiles", f"{rnd}_{tag}.json"), "w"), indent=1)
+    print(tag, "%.0f steps/s, %.2f ms/step" % (bench["value"], bench["ms_per_step"]))
