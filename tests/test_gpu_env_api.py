@@ -514,3 +514,64 @@ def test_record_arrays_are_sized_after_the_pre_launch_hook():
     assert float(eng.alphas.sum()) > 0
     obs2 = eng2.render_hard()  # camera_position = 0 there: only checks the pool/record path runs at this size
     assert torch.isfinite(obs2).all()
+
+
+@pytest.mark.parametrize("mesh,S", [("mixed", 128), ("teapot", 64), ("synthetic", 256)])
+def test_work_item_order_is_a_cost_sorted_permutation_of_all_tiles(mesh, S):
+    """OccWorkspace.order after a render (occ_setup_kernel + occ_order_kernel): the item list holds every tile of every
+    object's rect exactly once, queue by queue (env % 8), cost classes never increasing inside a queue - and the class
+    of a tile really bounds the face records whose pixel bbox touches it, which is what lets occ_raster2_kernel skip
+    the log for tiles of at most K faces."""
+    from tests.parity_utils import make_case
+    from occlusionenv_amd.engine import OcclusionEngine
+
+    N = 40
+    case = make_case(N, 77, mesh, az_range=2.0)
+    eng = OcclusionEngine(case["pool"], N, S)
+    eng.set_scene(list(range(N)), case["mesh_ids"], case["offsets"])
+    eng.reset_render(None, 4.0, case["az"], 0.0)
+    eng.check_status()
+    torch.cuda.synchronize()
+    order = eng._ws_tensors["order"].cpu().numpy().view(np.uint32)
+    nrec = eng._ws_tensors["nrec"].cpu().numpy()[: N * 3]
+    rect = eng._ws_tensors["objrect"].cpu().numpy()[: N * 12].reshape(N * 3, 4)
+    G = S // 8
+    T = G * G
+    tiles_w = 512 + N * 3 * 32
+    items_w = tiles_w + N * 3 * T
+    qoff = order[:9].astype(np.int64)
+    expect = {}  # (eo, local) -> (tx, ty)
+    for eo in range(N * 3):
+        x0, y0, x1, y1 = rect[eo]
+        if nrec[eo] <= 0 or x1 < x0 or y1 < y0:
+            continue
+        tx0, ty0, tw, th = x0 >> 1, y0 >> 1, (x1 >> 1) - (x0 >> 1) + 1, (y1 >> 1) - (y0 >> 1) + 1
+        for local in range(tw * th):
+            expect[(eo, local)] = (tx0 + local % tw, ty0 + local // tw)
+    assert qoff[0] == 0 and np.all(np.diff(qoff) >= 0) and qoff[8] == len(expect)
+    items = order[items_w: items_w + 2 * qoff[8]].reshape(-1, 2)
+    eos, local, cls = items[:, 0].astype(np.int64), (items[:, 1] & 0xFFFFFF).astype(np.int64), (items[:, 1] >> 24).astype(np.int64)
+    assert sorted(zip(eos.tolist(), local.tolist())) == sorted(expect)  # a permutation: nothing lost, nothing twice
+    for q in range(8):
+        sl = slice(qoff[q], qoff[q + 1])
+        assert np.all((eos[sl] // 3) % 8 == q)
+        assert np.all(np.diff(cls[sl]) <= 0)  # heaviest class first
+    assert cls.max() > cls.min()
+    # the class bounds the faces from above: count, per tile, the records whose pixel bbox touches it
+    rec_off = eng._rec_tensors["rec_off"].cpu().numpy().view(np.int64)
+    bbox = eng._rec_tensors["rec_bbox"].cpu().numpy().view(np.uint32).reshape(-1, 4)
+
+    def bound(c):  # occ_common.hpp: ord_class_bound
+        if c <= 0:
+            return 1
+        if c >= 31:
+            return 1 << 40
+        fl, half = (c - 1) >> 1, (c - 1) & 1
+        return 2 if fl == 0 else ((2 << fl) if half else (3 << (fl - 1)))
+
+    for k in np.random.default_rng(0).choice(len(items), size=min(400, len(items)), replace=False).tolist():
+        eo, (tx, ty) = int(eos[k]), expect[(int(eos[k]), int(local[k]))]
+        bb = bbox[rec_off[eo]: rec_off[eo] + nrec[eo]]
+        xl, yl, xh, yh = bb[:, 0] & 0xFFFF, bb[:, 0] >> 16, bb[:, 1] & 0xFFFF, bb[:, 1] >> 16
+        touching = int(np.count_nonzero((xl <= tx * 8 + 7) & (xh >= tx * 8) & (yl <= ty * 8 + 7) & (yh >= ty * 8)))
+        assert touching < bound(int(cls[k])), (eo, tx, ty, touching, int(cls[k]))
