@@ -57,12 +57,13 @@ constexpr int kListCap = 8;    // boundary-bucket entries per pixel that the own
 constexpr int kCopies = 4;     // accumulator copies (staged face & 3)
 constexpr int kAccStride = 65; // accumulator slots per copy: one per pixel, +1 so that the copies of a pixel differ mod 16 (acc_slot)
 
+constexpr uint32_t kNoEntry = 0xFFFFFFFFu;  // tag of a slot past the end of the log (a tag is pixel | face sequence number << 6)
 struct LogPay {  // 12 bytes, moved with one dwordx3 access
     float q, ge, ga;  // 1 - p, g_el, g_az
 };
 struct WaveLog {
     LogPay* __restrict__ pay;
-    uint2* __restrict__ kt;    // (order-preserving depth key, pixel of the tile 0..63)
+    uint2* __restrict__ kt;    // (order-preserving depth key, pixel of the tile 0..63 | face sequence number << 6)
 };
 
 // Accumulator slot of pixel pix (= 8 py + px) in copy cpy.  A 16-byte LDS access is served 16 lanes at a time, one per
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #pragma unroll
                 for (int u = 0; u < kSweepU; ++u) {
                     const int e = e0 + u * 64 + lane;
-                    kt[u] = e < nlog ? lg.kt[e] : make_uint2(0u, 255u);
+                    kt[u] = e < nlog ? lg.kt[e] : make_uint2(0u, kNoEntry);
                 }
             };
             constexpr int kGroup = 64 * kSweepU;
@@ -293,11 +294,12 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 auto bump = [&](const uint2 (&kt)[kSweepU]) __attribute__((always_inline)) {
 #pragma unroll
                     for (int u = 0; u < kSweepU; ++u) {
-                        if (kt[u].y < 64u) {
-                            const uint2 w = s_sel[kt[u].y];
+                        if (kt[u].y != kNoEntry) {
+                            const uint32_t px = kt[u].y & 63u;
+                            const uint2 w = s_sel[px];
                             if (w.y < 32u) {
                                 const uint32_t d = (kt[u].x - w.x) >> w.y;
-                                if (kt[u].x >= w.x && d < (1u << kSelBits)) atomicAdd(&hist[kt[u].y * kSelDw + (d >> 1)], 1u << (16 * (d & 1u)));
+                                if (kt[u].x >= w.x && d < (1u << kSelBits)) atomicAdd(&hist[px * kSelDw + (d >> 1)], 1u << (16 * (d & 1u)));
                             }
                         }
                     }
@@ -350,6 +352,10 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             s_take[lane] = mode == kAll ? 0x7FFFFFFFu : (uint32_t)max(need, 0);
             s_lcnt[lane] = 0u;  // kList: entries collected so far / compaction: largest kept key
             s_acc2[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ovf) {  // its accumulated sums are void: the copies now collect the log-domain sums of the kept entries
+#pragma unroll
+                for (int cpy = 0; cpy < kCopies; ++cpy) s_acc[cpy * kAccStride + myslot] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             uint2* blist = reinterpret_cast<uint2*>(s_pool);  // kList: (key, log index) x kListCap per pixel (histograms are done)
             __syncthreads();
             int wr = 0;
@@ -358,8 +364,9 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 LogPay pv[kSweepU];
 #pragma unroll
                 for (int u = 0; u < kSweepU; ++u) {  // decisions in log order (ties are served first come)
-                    if (kt[u].y < 64u) {
-                        const uint2 w = s_sel[kt[u].y];
+                    if (kt[u].y != kNoEntry) {
+                        const uint32_t px = kt[u].y & 63u;
+                        const uint2 w = s_sel[px];
                         const uint32_t shp = w.y & 255u;
                         if (shp >= 32u) {
                             keepm |= 1u << u;  // pixel not overflowing: its entries stay, its sums are already right
@@ -369,11 +376,11 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                                 r = true;
                             } else if (((kt[u].x - w.x) >> shp) == 0u) {
                                 if ((w.y >> 8) == (uint32_t)kList) {
-                                    const uint32_t sl = atomicAdd(&s_lcnt[kt[u].y], 1u);
-                                    if (sl < (uint32_t)kListCap) blist[kt[u].y * kListCap + sl] = make_uint2(kt[u].x, (uint32_t)(e0 + u * 64 + lane));
+                                    const uint32_t sl = atomicAdd(&s_lcnt[px], 1u);
+                                    if (sl < (uint32_t)kListCap) blist[px * kListCap + sl] = make_uint2(kt[u].x, (uint32_t)(e0 + u * 64 + lane));
                                 } else {
                                     // atomicSub returns the old value: the first `take` arrivals are kept
-                                    r = (int)atomicSub(&s_take[kt[u].y], 1u) > 0;
+                                    r = (int)atomicSub(&s_take[px], 1u) > 0;
                                 }
                             }
                             if (r) {
@@ -390,18 +397,35 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 }
 #pragma unroll
                 for (int u = 0; u < kSweepU; ++u) {
-                    if ((readdm >> u) & 1u) {
-                        const uint32_t t = kt[u].y & 63u;
-                        // product of the kept (1 - p_k) in the log domain: exp2(sum log2); log2(0) = -inf -> 0
-                        atomicAdd(&s_acc2[t].x, __builtin_amdgcn_logf(pv[u].q));
-                        if (GRAD) {
-                            atomicAdd(&s_acc2[t].y, pv[u].ge);
-                            atomicAdd(&s_acc2[t].z, pv[u].ga);
+                    {
+                        // Re-accumulate the kept entries - product of the (1 - p_k) in the log domain: exp2(sum log2);
+                        // log2(0) = -inf -> 0 - into the pixel's four accumulator copies by PLAIN read-modify-write,
+                        // as the evaluation rounds do: the tag carries the face's sequence number, faces 4 g .. 4 g + 3
+                        // use copies 0..3, and one sub-pass applies the lanes of one group g, so no two lanes of an
+                        // instruction share an address (three LDS float atomics per entry, colliding on the pixel,
+                        // cost 0.28 of the launch's 2.39 ms).
+                        const bool act = (readdm >> u) & 1u;
+                        const uint32_t tag = kt[u].y;
+                        const uint32_t grp = tag >> 8;
+                        const int slot = acc_slot((int)((tag >> 6) & 3u), (int)(tag & 63u));
+                        const float lq = __builtin_amdgcn_logf(pv[u].q);
+                        unsigned long long rem = __ballot(act);
+                        while (rem) {
+                            const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)grp, __ffsll(rem) - 1);
+                            const bool mine = act && grp == g0;
+                            if (mine) {
+                                float4 a = s_acc[slot];
+                                a.x += lq;
+                                if (GRAD) {
+                                    a.y += pv[u].ge;
+                                    a.z += pv[u].ga;
+                                }
+                                a.w += 1.0f;
+                                s_acc[slot] = a;
+                            }
+                            rem &= ~__ballot(mine);
                         }
-                        if (compact) {  // count and largest key only matter when the loop goes on
-                            atomicAdd(&s_acc2[t].w, 1.0f);
-                            atomicMax(&s_kmax2[t], kt[u].x);
-                        }
+                        if (compact && act) atomicMax(&s_kmax2[tag & 63u], kt[u].x);  // largest kept key (the loop goes on)
                     }
                     if (compact) {
                         const bool kp = (keepm >> u) & 1u;
@@ -432,6 +456,12 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 }
             }
             __syncthreads();
+            if (ovf) {  // fold the four copies in a fixed order
+                const float4 a0 = s_acc[myslot], a1 = s_acc[kAccStride + myslot], a2 = s_acc[2 * kAccStride + myslot],
+                             a3 = s_acc[3 * kAccStride + myslot];
+                s_acc2[lane] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
+                                           (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+            }
             OCC_T(13);  // selection: final sweep
             if (!compact && __ballot(mode == kList)) {
                 // the owner lane picks the `need` nearest of its <= kListCap boundary entries by (key, log index) and
@@ -546,6 +576,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 
         // ---- one staged batch: records -> LDS, pair expansion, evaluation rounds ------------------------------
         int nst = 0;  // staged faces (wave-uniform)
+        int fseq_base = 0;  // faces staged before this batch: sequence number of a face in the tile = fseq_base + its slot
         // records of the staged faces -> LDS (part-major).  Lane i of a group of 8 fetches part i of one record: the 8
         // loads of a record are one 128-byte line.  kStg2 * 8 / 64 = 4 loads per lane, issued together.
         constexpr int kStageLoads = kStg2 * kRecParts / 64;
@@ -715,7 +746,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #ifndef OCC_DBG2_NO_LOG  // timing experiment only
                             if (acc && !nolog) {
                                 const int e = nlog + lane_rank(m);
-                                lg.kt[e] = make_uint2(key, (uint32_t)pix);
+                                lg.kt[e] = make_uint2(key, (uint32_t)pix | (uint32_t)(fseq_base + f) << 6);
                                 lg.pay[e] = LogPay{c1.q, c1.ge, c1.ga};
                             }
 #endif
@@ -770,6 +801,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             for (int mm = 32; mm >= 1; mm >>= 1) bound = max(bound, (uint32_t)__shfl_xor((int)bound, mm, 64));
             thrB = (uint32_t)__builtin_amdgcn_readfirstlane((int)bound);
             OCC_T(6);  // pruning bounds
+            fseq_base += nst;
             return nst_next;
         };
 

@@ -3,14 +3,13 @@
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 run() {
   name=$1; shift
-  env "$@" timeout -k 10 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pool-models 64 2>/dev/null | python -c "
+  env "$@" timeout -k 10 100 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --pool-models 64 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         j = json.loads(l); print('$name', 'raster %.3f ms' % j['roofline']['avg_launch_ms'], 'step %.3f ms' % j['ms_per_step'], '%.0f steps/s' % j['value'])"
 }
-for r in 1 2; do
-  run inplace OCC_DEFER=0
-  run sort1k_inplace OCC_DEFER=0 OCC_HIP_LIB=$PWD/build/dbg2/libocc_sort1k.so
-  run sort1k_defer OCC_HIP_LIB=$PWD/build/dbg2/libocc_sort1k.so
+for r in 1 2 3; do
+  run before OCC_HIP_LIB=$PWD/build/dbg2/libocc_prev.so
+  run after X=1
 done
