@@ -282,10 +282,11 @@ def sigmoid_alpha_blend(dists, pix_to_face, sigma=SIGMA):
     return torch.cat([ones, alpha[..., None]], dim=-1)
 
 
-def soft_silhouette(verts_world, faces, R, T, S):
-    """silhouette_renderer(meshes_world=mesh, R=R, T=T) (environment.py:316-318,370-372)."""
+def soft_silhouette(verts_world, faces, R, T, S, K=K_SOFT):
+    """silhouette_renderer(meshes_world=mesh, R=R, T=T) (environment.py:316-318,370-372).  K = faces_per_pixel: the
+    reference's 100 (environment.py:79-83); the engine takes it as a parameter and the tests vary it."""
     ndc = world_to_ndc(verts_world, R, T)
-    p2f, _, _, dists = rasterize_meshes(ndc[faces], S, BLUR_RADIUS, K_SOFT)
+    p2f, _, _, dists = rasterize_meshes(ndc[faces], S, BLUR_RADIUS, K)
     return sigmoid_alpha_blend(dists, p2f)
 
 
@@ -459,7 +460,7 @@ class OracleEnv:
         obs_img, depth = self._observe(R, T)
         observation = obs_img[None].permute(0, 3, 1, 2).clone()
         observation[:, 3] = depth[None].permute(0, 3, 1, 2)[:, 0]
-        imgs = [soft_silhouette(v, f, R[0], T[0], S)[None] for v, f in self.objs]
+        imgs = [soft_silhouette(v, f, R[0], T[0], S, getattr(self, "faces_per_pixel", K_SOFT))[None] for v, f in self.objs]
         image = imgs[0] * imgs[1] + imgs[1] * imgs[2] + imgs[0] * imgs[2]
         return observation, image, imgs
 

@@ -77,7 +77,7 @@ def make_case(n_env, seed, mesh="teapot", az_range=0.6, pool=None, device="cuda"
     return dict(pool=pool, mesh_ids=mesh_ids, offsets=offsets, az=az, actions=actions)
 
 
-def oracle_env(case, i, img, shader="flat"):
+def oracle_env(case, i, img, shader="flat", faces_per_pixel=100):
     from oracle import p3d_restate as O
 
     objs, atl = [], []
@@ -88,6 +88,7 @@ def oracle_env(case, i, img, shader="flat"):
         atl.append(case["pool"].get_atlas(mid))
     env = O.OracleEnv(objs, img, atlases=atl if all(a is not None for a in atl) else None)
     env.shader = shader
+    env.faces_per_pixel = faces_per_pixel
     return env
 
 
@@ -254,7 +255,7 @@ def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_
     textured = mesh == "textured"
     orc, weights, unexplained, n_ties = {}, torch.ones(n_env, S, S), [], 0
     for i in envs:
-        env = oracle_env(case, i, img, shader)
+        env = oracle_env(case, i, img, shader, faces_per_pixel)
         obs0 = env.reset(radius=radius, azimuth=float(case["az"][i]))
         al0 = torch.stack([im[0, ..., 3] for im in env.alphas]).detach()
         img0 = env.image.detach()
@@ -308,7 +309,7 @@ def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_
         grel = float((g - got_w["grad"][i]).norm() / g.norm().clamp(min=1e-6))
         res["grad_rel"] = max(res["grad_rel"], grel)
         if grel >= TOL:  # fp32 cancellation noise or a real error?  the f64 oracle arbitrates (module docstring)
-            g64 = _oracle_grad64(case, i, img, radius, w)
+            g64 = _oracle_grad64(case, i, img, radius, w, faces_per_pixel)
             mass = gradient_mass(got_w, i, w)
             e_gpu = float((got_w["grad"][i].double() - g64).norm())
             e_orc = float((g.double() - g64).norm())
@@ -334,12 +335,13 @@ def gradient_mass(got, i, w):
     return float((got["jac"][i].abs().t() @ mass).norm() / float(got["object_mass"][i]))
 
 
-def _oracle_grad64(case, i, img, radius, w):
+def _oracle_grad64(case, i, img, radius, w, faces_per_pixel=100):
     """d reward / d action of env i from the f64 build of the oracle, loss weighted by w like the f32 comparison."""
     from oracle import p3d_restate as O
 
     e32 = oracle_env(case, i, img)
     env = O.OracleEnv([(v.double(), f) for v, f in e32.objs], img, dtype=torch.float64)
+    env.faces_per_pixel = faces_per_pixel
     env.reset(radius=radius, azimuth=float(case["az"][i]))
     wd = w.double()
     loss0 = torch.sum(wd * env.image[0, ..., 3].detach() ** 2)

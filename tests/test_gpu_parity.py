@@ -47,6 +47,13 @@ def test_mixed_face_counts_128():  # 1280 / 5120 / 20480-face meshes in one batc
     _check(run_parity_case(n_env=2, img=128, seed=6, mesh="mixed", az_range=3.0))
 
 
+@pytest.mark.parametrize("K", [8, 30])
+def test_small_faces_per_pixel(K):
+    """K far below the default: nearly every covered pixel overflows (exact top-K everywhere), and the cost classes
+    that let a tile go without a log (at most K faces touch it) are the lowest ones."""
+    _check(run_parity_case(n_env=2, img=64, seed=12, mesh="teapot", faces_per_pixel=K))
+
+
 def test_z_clipped_scene():
     # camera 1.2 from the origin: faces straddle z = 0.5 -> clip_faces cases 3 / 4 and the pair rule (A.3)
     _check(run_parity_case(n_env=2, img=64, seed=7, mesh="teapot", az_range=0.3, radius=1.2))
