@@ -303,7 +303,7 @@ __device__ __forceinline__ void topk_select4(float4* __restrict__ list, uint32_t
 
 #ifdef OCC_DBG_STATS  // diagnostic build only: loop trip counts of the raster kernel
 __device__ unsigned long long g_dbg_stats[8];
-#define OCC_STAT(i, v) do { if (lane == 0) atomicAdd(&g_dbg_stats[i], (unsigned long long)(v)); } while (0)
+#define OCC_STAT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); /* all lanes: v may hold a ballot */ if (lane == 0) atomicAdd(&g_dbg_stats[i], v_); } while (0)
 #else
 #define OCC_STAT(i, v) do { } while (0)
 #endif
