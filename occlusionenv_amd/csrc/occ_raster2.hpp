@@ -1,4 +1,5 @@
-// occ_raster2.hpp -- pair-enumerating raster kernel (round 2): one persistent wave64 per (env, object, 8x8-pixel tile).
+// occ_raster2.hpp -- pair-enumerating raster kernel (round 2): persistent wave64s, work item = (env, object, 8x8-pixel
+// tile), taken heaviest first from the XCD's queue (occ_order_kernel).
 // Part of the single translation unit occ_kernels.hip (included inside namespace occ; not a stand-alone header).
 //
 // What changed against occ_raster.hpp (4x4-pixel block x 4 face slots, every staged face evaluated at all 16 pixels,
@@ -20,9 +21,10 @@
 //     folds the four copies in a fixed order: results are reproducible and independent of the batch.  Nearest hard
 //     face: one 64-bit LDS atomic min of (depth key << 32 | record) per INSIDE pair (few).
 //   * K-BUFFER = WAVE-COMPACTED LOG.  Accepted candidates of a round are appended contiguously (ballot rank) to the
-//     wave's log in HBM/L2: (key, owning pixel) 8 B + payload (1 - p, g_el, g_az) 16 B - full-line coalesced stores
-//     instead of 64 partial lines (measured: free next to the evaluation).  The log is only read when some pixel of
-//     the tile collected more than K candidates.
+//     wave's log in HBM/L2: (key, owning pixel | face sequence number << 6) 8 B + payload (1 - p, g_el, g_az) 12 B -
+//     full-line coalesced stores instead of 64 partial lines (measured: free next to the evaluation).  The log is only
+//     read when some pixel of the tile collected more than K candidates, and not even written for a tile that at most
+//     K faces touch (its cost class, carried by the work item, says so).
 //   * BATCHES ARE PIPELINED.  While a batch of <= 32 faces is evaluated, the scan has already produced the next
 //     batch's hit list (second list in LDS) and its records are in flight into registers; they are committed to LDS
 //     when the next batch starts, behind an explicit s_waitcnt + sched_barrier (left to itself hipcc hoists the next
@@ -31,10 +33,16 @@
 //   * COOPERATIVE EXACT TOP-K.  Radix select (5 bits per level) over the log with all 64 lanes sweeping it
 //     contiguously; every entry bumps the LDS histogram of ITS pixel; the pixel's owner lane (lane = pixel) scans its
 //     32 buckets and narrows its window; sweeps keep two groups of four 512-byte loads in flight (a sweep with one
-//     dependent load per iteration is pure memory latency).  Afterwards one more sweep re-accumulates the kept entries of the
-//     overflowing pixels (log-domain product via LDS atomics: <= K entries per such pixel; replacing those atomics by
-//     rank-by-pixel plain read-modify-write - six ballots per row - was measured and is slower).  When the log fills up (thousands of candidates per pixel: far cameras, dense meshes) the
-//     same machinery keeps each overflowing pixel's K nearest and compacts the log in place; pruning bounds as before.
+//     dependent load per iteration is pure memory latency).  Afterwards one more sweep re-accumulates the kept entries
+//     of the overflowing pixels (log-domain product) into the pixel's four accumulator copies by plain
+//     read-modify-write, one sub-pass per group of four faces (the tag's sequence number): three LDS float atomics per
+//     entry, colliding on the pixel, cost 0.28 of 2.39 ms; ranking the lanes of a row by pixel with six ballots was
+//     slower still.  When the log fills up (thousands of candidates per pixel: far cameras, dense meshes) the same
+//     machinery keeps each overflowing pixel's K nearest and compacts the log in place; pruning bounds as before.
+//   * TWELVE RESIDENT WAVES PER CU need <= 12.3 KB of LDS each (12 240 B here; with 13 648 B one wave in twelve only
+//     started when another had finished): one accumulator slot per pixel with a rotated column, 16-bit key bounds,
+//     the per-pixel bound of dense objects read from its owner lane.  The kernel is latency-bound: 10 / 11 / 12 waves
+//     per CU = 2.66 / 2.52 / 2.42 ms.
 //
 // Semantics are those of occ_raster.hpp: same eval_face, same candidate rule, same K-nearest-by-z
 // truncation, same clipped-pair rule, same hard nearest-face rule.
@@ -46,7 +54,7 @@ static_assert(OCC_LOG_CAP >= 64 * OCC_MAX_K + 2048 + 64, "OCC_LOG_CAP too small"
 #define OCC_LOG_BYTES ((size_t)OCC_LOG_CAP * 20)  // 12 B payload + 8 B (key, pixel)
 
 constexpr int kT2 = 8;         // tile side in pixels (== OCC_TILE)
-constexpr int kStg2 = 32;      // faces staged per batch (LDS budget: 12 waves per CU need <= 13.3 KB each)
+constexpr int kStg2 = 32;      // faces staged per batch (LDS budget: 12 resident waves per CU need <= 12.3 KB each)
 constexpr int kStgPad = 33;    // LDS stride (float4) between the parts of the staged records (odd: conflict-free staging)
 constexpr int kPairCap = 2048; // pairs per batch at most (kStg2 faces x 64 pixels): one byte each in the pair map
 constexpr int kSelBits = 5;    // radix-select digit: 32 u16 buckets = 16 dwords per pixel (4 KB, aliasing records + descriptors)
