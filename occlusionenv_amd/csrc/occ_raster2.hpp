@@ -39,8 +39,8 @@
 //     entry, colliding on the pixel, cost 0.28 of 2.39 ms; ranking the lanes of a row by pixel with six ballots was
 //     slower still.  When the log fills up (thousands of candidates per pixel: far cameras, dense meshes) the same
 //     machinery keeps each overflowing pixel's K nearest and compacts the log in place; pruning bounds as before.
-//   * TWELVE RESIDENT WAVES PER CU need <= 12.3 KB of LDS each (12 240 B here; with 13 648 B one wave in twelve only
-//     started when another had finished): one accumulator slot per pixel with a rotated column, 16-bit key bounds,
+//   * TWELVE RESIDENT WAVES PER CU need <= 12.5 KB of LDS each (12 752 B still fits, 13 008 B does not; 12 240 B here;
+//     with 13 648 B one wave in twelve only started when another had finished): one accumulator slot per pixel with a rotated column, 16-bit key bounds,
 //     the per-pixel bound of dense objects read from its owner lane.  The kernel is latency-bound: 10 / 11 / 12 waves
 //     per CU = 2.66 / 2.52 / 2.42 ms.
 //
@@ -54,7 +54,7 @@ static_assert(OCC_LOG_CAP >= 64 * OCC_MAX_K + 2048 + 64, "OCC_LOG_CAP too small"
 #define OCC_LOG_BYTES ((size_t)OCC_LOG_CAP * 20)  // 12 B payload + 8 B (key, pixel)
 
 constexpr int kT2 = 8;         // tile side in pixels (== OCC_TILE)
-constexpr int kStg2 = 32;      // faces staged per batch (LDS budget: 12 resident waves per CU need <= 12.3 KB each)
+constexpr int kStg2 = 32;      // faces staged per batch (LDS budget: 12 resident waves per CU need <= 12.5 KB each)
 constexpr int kStgPad = 33;    // LDS stride (float4) between the parts of the staged records (odd: conflict-free staging)
 constexpr int kPairCap = 2048; // pairs per batch at most (kStg2 faces x 64 pixels): one byte each in the pair map
 constexpr int kSelBits = 5;    // radix-select digit: 32 u16 buckets = 16 dwords per pixel (4 KB, aliasing records + descriptors)
