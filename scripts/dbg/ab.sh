@@ -9,7 +9,7 @@ for l in sys.stdin:
     if l.startswith('{'):
         j = json.loads(l); print('$name', 'raster %.3f ms' % j['roofline']['avg_launch_ms'], 'step %.3f ms' % j['ms_per_step'], '%.0f steps/s' % j['value'])"
 }
-for r in 1 2; do
-  run head X=1
-  run hist_twice OCC_HIP_LIB=$PWD/build/dbg2/libocc_HT.so
+for r in 1 2 3; do
+  run before OCC_HIP_LIB=$PWD/build/dbg2/libocc_prev.so
+  run after X=1
 done
