@@ -140,9 +140,10 @@ class BatchedPPO:
 
 
 def train_rollouts(venv, agent: BatchedPPO, n_updates: int = 1, T: int = 50, with_action_grad: bool = False,
-                   generator: Optional[torch.Generator] = None) -> list:
+                   generator: Optional[torch.Generator] = None, on_step=None) -> list:
     """trainRL.py:189-229, batched: T vectorised steps (auto-reset inside the env) -> one PPO update; repeated.
-    Returns the per-update stats (mean reward, loss before/after)."""
+    Returns the per-update stats (mean reward, loss before/after).  ``on_step(action, rewards)`` is called after every
+    step (and its backward): the hook of callers that consume ``action.grad`` (train_predict.py:52-58)."""
     obs = venv.reset()[:, 0]
     stats = []
     for _ in range(n_updates):
@@ -153,6 +154,8 @@ def train_rollouts(venv, agent: BatchedPPO, n_updates: int = 1, T: int = 50, wit
             obs, rewards, dones, _infos = venv.step(action)
             if with_action_grad:
                 rewards.sum().backward()
+            if on_step is not None:
+                on_step(action, rewards)
             rec = rollout.pack_records(obs, action, logprob, rewards, dones)
             rec[:, :256] = feats  # the state that produced the action (PPO.py:158), not the next one
             agent.store(rollout.all_gather_records(rec))

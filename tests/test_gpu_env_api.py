@@ -286,6 +286,36 @@ def test_ppo_rollout_and_update_end_to_end(ds):
     assert all(np.isfinite(st["loss_first"]) and np.isfinite(st["loss_last"]) and np.isfinite(st["mean_reward"]) for st in stats)
 
 
+def test_config5_per_rank_ppo_rollout_and_update():
+    """BASELINE config 5 at its per-rank size (2 048 envs over 8 GPUs = 256 envs/GPU, 256x256): one rollout of T = 50
+    vectorised steps with the differentiable-reward backward to the action, then one heads-only PPO update
+    (/root/reference/trainRL.py:189-229, PPO.py:152-223)."""
+    from occlusionenv_amd import ppo
+    from occlusionenv_amd.meshes import SyntheticShapeNet
+    from environment import OcclusionEnv
+    from SubProcVecEnv import SimpleVecEnv
+
+    N, T, S = 256, 50, 256
+    pool = SyntheticShapeNet(n_models=64, seed=1234)
+    venv = SimpleVecEnv([lambda: OcclusionEnv(pool, img_size=S) for _ in range(N)])
+    agent = ppo.BatchedPPO(device="cuda", seed=0)  # trainRL.py hyper-parameters: 80 epochs, clip 0.2, gamma 0.99
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    grads = []
+    stats = ppo.train_rollouts(venv, agent, n_updates=1, T=T, with_action_grad=True, generator=gen,
+                               on_step=lambda action, rewards: grads.append(action.grad.detach().clone()))
+    assert len(stats) == 1 and stats[0]["samples"] == T * N
+    st = stats[0]
+    assert np.isfinite(st["loss_first"]) and np.isfinite(st["loss_last"]) and np.isfinite(st["mean_reward"])
+    assert st["loss_last"] < st["loss_first"]  # 80 epochs on the heads reduce the clipped-surrogate + value loss
+    g = torch.stack(grads)
+    assert g.shape == (T, N, 2) and torch.isfinite(g).all() and float(g.abs().max()) > 0.0
+    venv._drain()
+    venv.engine.check_status()  # no status word set by any kernel of the 50 steps
+    assert int(venv.engine.status.abs().max()) == 0
+    for p_new, p_old in zip(agent.policy.parameters(), agent.policy_old.parameters()):
+        assert torch.equal(p_new, p_old) and torch.isfinite(p_new).all()
+
+
 def test_dataset_generator_and_no_grad_steps(ds, tmp_path):
     """datasetGenerator.py:76-124 batched (4 runs x 3 frames) + the reader; steps without autograd use the
     gradient-free kernel variants."""
