@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define OCC_ABI_VERSION 5
+#define OCC_ABI_VERSION 6
 
 /* return codes */
 #define OCC_OK 0
@@ -56,10 +56,12 @@ extern "C" {
 #define OCC_CAM_STRIDE 48  /* floats per env in the camera buffer */
 #define OCC_REC_STRIDE 32  /* floats per projected-face record (eight 16-byte parts = one 128-byte line) */
 #define OCC_TILE 8         /* image sides must be a multiple of this */
-#define OCC_BLOCK 4        /* pixels per block side: one wave64 work item = 4x4 pixels x 4 face slots */
-#ifndef OCC_LIST_CAP
-#define OCC_LIST_CAP 512   /* per-pixel candidate list capacity; a full list is compacted in place to its K nearest */
+#define OCC_BLOCK 4        /* unit of OccWorkspace.objrect: 4x4-pixel blocks (a raster work item = 2x2 blocks = one 8x8 tile) */
+#ifndef OCC_LOG_CAP
+#define OCC_LOG_CAP 12288  /* candidate-log entries per persistent wave (20 B each); a log about to fill up is compacted
+                              in place to every overflowing pixel's K nearest.  Must be >= 64*OCC_MAX_K + 2048 + 64 */
 #endif
+#define OCC_LOG_ENTRY_BYTES 20 /* (depth key u32, pixel | face sequence << 6 u32) + payload (1-p, p dd/del, p dd/daz) f32 x3 */
 #define OCC_MAX_K 128      /* largest faces_per_pixel the fused path accepts */
 
 /* occ_camera modes */
@@ -117,16 +119,17 @@ typedef struct OccWorkspace {
     int32_t* nrec;      /* (n_env,3) */
     int32_t* objrect;   /* (n_env,3,4) block rect bx0,by0,bx1,by1 (inclusive, OCC_BLOCK-pixel units) */
     uint32_t* queue;    /* (8,16) one work-queue head per XCD group, a 64-B line each (zeroed by occ_render) */
-    float* lists;       /* (n_slots,OCC_LIST_CAP,64,4) per-wave K-buffer rows: (key(z) u32, 1-p, g_el, g_az) per lane */
+    float* lists;       /* (n_slots, OCC_LOG_CAP*OCC_LOG_ENTRY_BYTES) per-wave K-buffer = wave-compacted candidate log:
+                           OCC_LOG_CAP payloads of 12 B, then OCC_LOG_CAP (key, tag) pairs of 8 B (structure of arrays) */
     float* partials;    /* (n_env,ceil(S*S/256),4) per-block loss / gradient partial sums */
     int32_t* status;    /* (n_env) OCC_STATUS_* bits, OR-ed in; caller clears */
-    int32_t* offsets;   /* (8*3*ceil(n_env/8)+1) first work item of every (env, object), XCD-major order */
+    int32_t* offsets;   /* (8*3*ceil(n_env/8)+1) rect order only (order == NULL): first work item of every (env, object), XCD-major */
     uint32_t* rec_cbox; /* (n_env,3,ceil(rec_cap/64),4) union pixel bbox + nearest depth key of every 64-entry scan chunk */
     float* obj_alpha;   /* (n_env,3,S,S) per-object silhouette alpha, valid inside the object's tile rect */
     float* obj_grad;    /* (n_env,3,S,S,2) d alpha / d(el, az) */
     float* obj_hz;      /* (n_env,3,S,S) depth of the nearest face of the object (3e38 = none) */
     int32_t* obj_hrec;  /* (n_env,3,S,S) its record index, -1 = none */
-    int32_t n_slots;    /* persistent waves = blocks the tile kernel is launched with */
+    int32_t n_slots;    /* persistent waves = blocks occ_raster2_kernel is launched with */
     /* Optional variable record layout: rec / rec_bbox / scan hold rec_total records in all and every (env, object)
      * gets room for ITS mesh (2 x faces, rounded up to 64) at record offset rec_off[env*3+obj]; rec_off
      * (3*n_env+1 int64) is filled by occ_render.  NULL = fixed stride rec_cap per (env, object). */
@@ -138,7 +141,8 @@ typedef struct OccWorkspace {
      *   [0..8] first item of every XCD queue and the total, [16 + 32 q + c] tiles of cost class c in queue q,
      *   [512 + 32 (env*3+obj) + c] where the object's class-c tiles start inside the class,
      *   then (n_env,3,T) per tile: rank inside the object's class << 5 | class   (T = (S/8)^2 tiles per image),
-     *   then (n_env*3*T) items (env*3+obj, tile index inside the object's rect | class << 24), 8 B each.
+     *   then (one pad word if needed for 8-byte alignment and) (n_env*3*T) items
+     *   (env*3+obj, tile index inside the object's rect | class << 24), 8 B each.
      * occ_render zeroes the first 512 words. */
     uint32_t* order;
 } OccWorkspace;
@@ -307,7 +311,7 @@ int occ_reserve_refill(const int32_t* packed, int n, int n_env, int n_reserve, i
 
 /*
  * Measurement hooks (bench.py only; not part of the reference surface).  While enabled, occ_render
- * brackets its dominant kernel (occ_raster_kernel) with HIP events on the launch stream.
+ * brackets its dominant kernel (occ_raster2_kernel) with HIP events on the launch stream.
  * occ_profile_read synchronises the recorded events (host sync!), returns the summed duration in
  * milliseconds and the number of launches since the last read -- counting only the launches with the
  * largest n_env seen (full batches; auto-resets render tiny ones) -- and resets the ring (max 4096 launches).

@@ -9,15 +9,16 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# OCC_HIP_LIB selects another build of the SAME sources (tests use a small-OCC_LIST_CAP build); never a fallback
+# OCC_HIP_LIB selects another build of the SAME sources (tests use a small-OCC_LOG_CAP build); never a fallback
 LIB_PATH = os.environ.get("OCC_HIP_LIB") or os.path.join(_HERE, "libocc_hip.so")
 
 # layout constants (must match include/occlusionenv_amd.h)
-ABI_VERSION = 5
+ABI_VERSION = 6
 CAM_STRIDE = 48
 REC_STRIDE = 32
 TILE = 8
-LIST_CAP = 512
+LOG_CAP = 12288
+LOG_ENTRY_BYTES = 20
 MAX_K = 128
 CAM_STEP, CAM_LOOKAT, CAM_POSITION = 0, 1, 2
 RENDER_SOFT, RENDER_HARD, RENDER_GRAD = 1, 2, 4

@@ -22,8 +22,9 @@ constexpr int kOrdCounts = 16;    // [16 + 32 q + c]: tiles of cost class c in X
 constexpr int kOrdClasses = 32;
 constexpr int kOrdBlk = 512;      // [512 + 32 eo + c]: start of object eo's class-c tiles inside the class
 __host__ __device__ __forceinline__ size_t ord_tiles_word(int n_env) { return (size_t)kOrdBlk + (size_t)n_env * 3 * kOrdClasses; }
+// the item list is read as uint2: its first word is even (one pad word when the tile table ends on an odd word)
 __host__ __device__ __forceinline__ size_t ord_items_word(int n_env, int img) {
-    return ord_tiles_word(n_env) + (size_t)n_env * 3 * (img / 8) * (img / 8);
+    return (ord_tiles_word(n_env) + (size_t)n_env * 3 * (img / 8) * (img / 8) + 1) & ~(size_t)1;
 }
 // cost class of a tile that c faces touch: two classes per octave, 0 = empty
 __device__ __forceinline__ int ord_class(uint32_t c) {

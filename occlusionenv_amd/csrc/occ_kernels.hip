@@ -9,13 +9,14 @@
 //                       (MeshRasterizer.transform), z-clip (clip_faces), cull, per-face record
 //                       with NDC verts + tangents + invariants, ORDERED compaction (face order is
 //                       PyTorch3D's tie-break order), packed tile bbox, object tile rect
-//   occ_scan_kernel     prefix sum of the rect areas -> work items (env, object, block inside the rect)
-//   occ_raster_kernel   persistent wave64 per work item (env, object, 4x4-pixel block): 16 pixels x 4 face
-//                       slots per wave (on-the-fly binning by ballot over pixel bboxes, records staged in
-//                       LDS by cooperative 16-B loads): soft silhouette (K nearest-z
-//                       sigmoid product) + hard nearest face of ONE object in one sweep, candidate K-buffer
-//                       (z, 1-p, grad) streamed to HBM/L2 in 1-KiB coalesced rows, exact top-K-by-z
-//                       selection (LDS-histogram radix select) when a pixel has more than K candidates
+//   occ_order_kernel    work items (env, object, 8x8-pixel tile) in cost order, heaviest first per XCD queue
+//                       (occ_scan_kernel: plain rect order when the workspace has no order buffer)
+//   occ_raster2_kernel  persistent wave64 per work item: lane = (face, pixel) PAIR over the pixels of every face's
+//                       pixel bbox inside the tile (on-the-fly binning by ballot over chunk boxes and pixel bboxes,
+//                       records staged in LDS by cooperative 16-B loads): soft silhouette (K nearest-z sigmoid
+//                       product) + hard nearest face of ONE object in one sweep, per-pixel state in LDS, candidate
+//                       K-buffer = wave-compacted log streamed to HBM/L2 in full lines, exact top-K-by-z selection
+//                       (cooperative LDS-histogram radix select) when a pixel has more than K candidates
 //   occ_combine_kernel  one thread per pixel: occlusion image of the three silhouettes, loss and
 //                       d loss/d(el,az) partials, nearest-object pick + flat shading, outputs
 //   occ_reduce_kernel   one wave per env: fixed-order sum of the per-block partials
@@ -39,7 +40,7 @@ namespace occ {
 #include "occ_common.hpp"
 #include "occ_camera.hpp"
 #include "occ_setup.hpp"
-#include "occ_raster.hpp"
+#include "occ_eval.hpp"
 #include "occ_raster2.hpp"
 #include "occ_combine.hpp"
 #include "occ_blend.hpp"
@@ -149,10 +150,7 @@ extern "C" int occ_workspace_query(const OccScene* scene, int n_slots, OccWorksp
     out->nrec_bytes = N * 3 * sizeof(int32_t);
     out->objrect_bytes = N * 3 * 4 * sizeof(int32_t);
     out->queue_bytes = 8 * 16 * sizeof(uint32_t);  // eight queue heads, one 64-B line each
-    {   // per-wave K-buffer: lane lists (occ_raster_kernel) or compacted log (occ_raster2_kernel)
-        const size_t a = (size_t)OCC_LIST_CAP * 64 * 4 * sizeof(float), b = OCC_LOG_BYTES;
-        out->lists_bytes = (size_t)n_slots * (a > b ? a : b);
-    }
+    out->lists_bytes = (size_t)n_slots * OCC_LOG_BYTES;  // per-wave K-buffer: the compacted candidate log
     const size_t S2 = (size_t)scene->img * scene->img;
     out->partials_bytes = N * ((S2 + 255) / 256) * 4 * sizeof(float);
     out->offsets_bytes = (size_t)(8 * xcd_slots(scene->n_env) + 1) * sizeof(int32_t);
@@ -165,7 +163,7 @@ extern "C" int occ_workspace_query(const OccScene* scene, int n_slots, OccWorksp
     out->rec_off_bytes = (N * 3 + 1) * sizeof(int64_t);
     {   // work-item order: header + per-object class offsets + per-tile (rank, class) + the item list
         const size_t T = (size_t)(scene->img / 8) * (scene->img / 8);
-        out->order_bytes = (kOrdBlk + N * 3 * kOrdClasses + N * 3 * T * 3) * sizeof(uint32_t);
+        out->order_bytes = (ord_items_word(scene->n_env, scene->img) + N * 3 * T * 2) * sizeof(uint32_t);
     }
     return OCC_OK;
 }
@@ -194,28 +192,7 @@ extern "C" int occ_camera(int mode, const float* action, float* el, float* az, c
 }
 
 // OCC_DEBUG_SYNC=1 in the environment: every launch of occ_render is announced on stderr and waited for, so that a
-// faulting kernel is the last one named (diagnostics only; serialises the stream).
-// OCC_RASTER=1 selects the round-1 raster kernel (4x4 blocks x 4 face slots), anything else the pair-enumerating
-// 8x8-tile kernel (occ_raster2.hpp).  Both implement the same semantics; kept for A/B measurements.
-static int raster_variant() {
-    static int v = 0;
-    if (!v) {
-        const char* e = getenv("OCC_RASTER");
-        v = (e && e[0] == '1') ? 1 : 2;
-    }
-    return v;
-}
-
-// OCC_ORDER=0: work items of occ_raster2_kernel in rect order even when the workspace has an order buffer (A/B timing)
-static bool order_enabled() {
-    static int v = 0;
-    if (!v) {
-        const char* e = getenv("OCC_ORDER");
-        v = (e && e[0] == '0') ? 1 : 2;
-    }
-    return v == 2;
-}
-
+// faulting kernel is the last one named (diagnostics only; serialises the stream).  The only getenv of the library.
 static bool dbg_sync_on() {
     static int on = -1;
     if (on < 0) {
@@ -250,9 +227,7 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(ws->queue, 0, 8 * 16 * sizeof(uint32_t), st) != hipSuccess) return OCC_ERR_LAUNCH;
     const int N = scene->n_env;
-    const int rv = raster_variant();
-    OccWorkspace wsv = *ws;  // the kernels' view of the workspace
-    if (rv != 2 || !order_enabled()) wsv.order = nullptr;
+    const OccWorkspace& wsv = *ws;
     if (wsv.order && hipMemsetAsync(wsv.order, 0, kOrdBlk * sizeof(uint32_t), st) != hipSuccess) return OCC_ERR_LAUNCH;
     if (ws->rec_off) {
         if (ws->rec_total <= 0 || (ws->rec_total & 63)) return OCC_ERR_ARG;
@@ -284,7 +259,7 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
         hipLaunchKernelGGL(occ_order_kernel, dim3(N * 3), dim3(64), 0, st, ws->objrect, ws->nrec, wsv.order, N, scene->img);
         OCC_DBG_SYNC("order");
     } else {
-        hipLaunchKernelGGL(occ_scan_kernel, dim3(1), dim3(1024), 0, st, ws->objrect, ws->nrec, ws->offsets, N, rv == 2 ? 1 : 0);
+        hipLaunchKernelGGL(occ_scan_kernel, dim3(1), dim3(1024), 0, st, ws->objrect, ws->nrec, ws->offsets, N, 1);
         OCC_DBG_SYNC("scan");
     }
     if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
@@ -295,10 +270,7 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
     const dim3 cgrid(N * bpe), cblock(256);
 #define OCC_LAUNCH(SOFT_, HARD_, GRAD_)                                                             \
     do {                                                                                            \
-        if (rv == 2)                                                                                \
-            hipLaunchKernelGGL((occ_raster2_kernel<SOFT_, HARD_, GRAD_>), grid, block, 0, st, P);   \
-        else                                                                                        \
-            hipLaunchKernelGGL((occ_raster_kernel<SOFT_, HARD_, GRAD_>), grid, block, 0, st, P);    \
+        hipLaunchKernelGGL((occ_raster2_kernel<SOFT_, HARD_, GRAD_>), grid, block, 0, st, P);       \
         OCC_DBG_SYNC("raster");                                                                     \
         if (prof) {                                                                                 \
             (void)hipEventRecord(g_prof_ev[2 * g_prof_n + 1], st);                                  \

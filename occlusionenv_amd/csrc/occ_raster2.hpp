@@ -47,11 +47,11 @@
 // Semantics are those of occ_raster.hpp: same eval_face, same candidate rule, same K-nearest-by-z
 // truncation, same clipped-pair rule, same hard nearest-face rule.
 
-#ifndef OCC_LOG_CAP
-#define OCC_LOG_CAP 12288  // log entries per wave; must hold a compacted log (64 * OCC_MAX_K) plus the pairs of one batch
-#endif
+// OCC_LOG_CAP (include/occlusionenv_amd.h): log entries per wave; must hold a compacted log (64 * OCC_MAX_K) plus the
+// pairs of one batch
 static_assert(OCC_LOG_CAP >= 64 * OCC_MAX_K + 2048 + 64, "OCC_LOG_CAP too small");
-#define OCC_LOG_BYTES ((size_t)OCC_LOG_CAP * 20)  // 12 B payload + 8 B (key, pixel)
+static_assert(OCC_LOG_ENTRY_BYTES == 20, "12 B payload + 8 B (key, tag)");
+#define OCC_LOG_BYTES ((size_t)OCC_LOG_CAP * OCC_LOG_ENTRY_BYTES)
 
 constexpr int kT2 = 8;         // tile side in pixels (== OCC_TILE)
 constexpr int kStg2 = 32;      // faces staged per batch (LDS budget: 12 resident waves per CU need <= 12.5 KB each)

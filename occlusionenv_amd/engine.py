@@ -21,6 +21,9 @@ from . import _native as nat
 from .meshes import MeshPool
 
 
+WAVES_PER_CU = 12  # resident persistent waves per CU of occ_raster2_kernel (3 per SIMD at <= 168 VGPRs, 12.2 KB LDS each)
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -45,7 +48,7 @@ class OcclusionEngine:
     """State + workspace of N environments on one GPU."""
 
     def __init__(self, pool: MeshPool, n_env: int, img_size: int, device=None, faces_per_pixel: int = 100,
-                 waves_per_cu: Optional[int] = None, reserve: int = 0):
+                 waves_per_cu: Optional[int] = None, reserve: int = 0, cost_order: bool = True):
         self.lib = nat.load()
         if not torch.cuda.is_available():
             raise nat.NativeError("OcclusionEngine needs a ROCm GPU (torch.cuda.is_available() is False); "
@@ -59,10 +62,10 @@ class OcclusionEngine:
         self.N = int(n_env)
         self.S = int(img_size)
         self.K = int(faces_per_pixel)
-        # persistent waves per CU of the raster kernel: what its LDS / VGPR budget admits (occ_raster2_kernel: 13.3 KB
-        # of LDS and <= 168 VGPRs per wave -> 12; the round-1 kernel, OCC_RASTER=1: 20)
-        default_wpc = 20 if os.environ.get("OCC_RASTER", "")[:1] == "1" else 12
-        self.waves_per_cu = int(waves_per_cu or os.environ.get("OCC_WAVES_PER_CU", default_wpc))
+        # persistent waves per CU of the raster kernel: what its LDS / VGPR budget admits (occ_raster2.hpp)
+        self.waves_per_cu = int(waves_per_cu or os.environ.get("OCC_WAVES_PER_CU", WAVES_PER_CU))
+        # work items heaviest first (occ_order_kernel); False = plain rect order (OccWorkspace.order = NULL)
+        self.cost_order = bool(cost_order)
         d = self.device
         f32 = dict(dtype=torch.float32, device=d)
         N = self.N
@@ -203,7 +206,8 @@ class OcclusionEngine:
                      order=buf(sizes.order_bytes))
             ws = nat.OccWorkspace()
             for k, v in t.items():
-                setattr(ws, k, v.data_ptr())
+                if k != "order" or self.cost_order:
+                    setattr(ws, k, v.data_ptr())
             ws.n_slots = sizes.n_slots
             self._ws, self._ws_tensors, self._ws_key = ws, t, key
             self._rec_tensors, self._rec_total = None, 0

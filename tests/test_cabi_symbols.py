@@ -42,7 +42,7 @@ def test_binding_constants_match_header():
 
     assert define("OCC_ABI_VERSION") == nat.ABI_VERSION and define("OCC_CAM_STRIDE") == nat.CAM_STRIDE
     assert define("OCC_REC_STRIDE") == nat.REC_STRIDE and define("OCC_TILE") == nat.TILE
-    assert define("OCC_LIST_CAP") == nat.LIST_CAP and define("OCC_MAX_K") == nat.MAX_K
+    assert define("OCC_LOG_CAP") == nat.LOG_CAP and define("OCC_LOG_ENTRY_BYTES") == nat.LOG_ENTRY_BYTES and define("OCC_MAX_K") == nat.MAX_K
     assert (define("OCC_RENDER_SOFT"), define("OCC_RENDER_HARD"), define("OCC_RENDER_GRAD")) == (1, 2, 4)
     assert (define("OCC_CAM_STEP"), define("OCC_CAM_LOOKAT"), define("OCC_CAM_POSITION")) == (0, 1, 2)
 
@@ -58,9 +58,14 @@ def test_workspace_query_and_argument_checks_need_no_gpu():
     assert sizes.rec_bytes == 4 * 3 * 1000 * nat.REC_STRIDE * 4 and sizes.rec_bbox_bytes == 4 * 3 * 1000 * 16 and sizes.scan_bytes == sizes.rec_bbox_bytes
     assert sizes.partials_bytes == 4 * 64 * 16 and sizes.n_slots == 64
     assert sizes.offsets_bytes == 25 * 4 and sizes.queue_bytes == 512 and sizes.obj_alpha_bytes == 4 * 3 * 128 * 128 * 4 and sizes.obj_grad_bytes == 2 * sizes.obj_alpha_bytes
-    assert sizes.lists_bytes == 64 * nat.LIST_CAP * 64 * 16
+    assert sizes.lists_bytes == 64 * nat.LOG_CAP * nat.LOG_ENTRY_BYTES  # sized for the log only
     # work-item order: 512 header words + 32 per (env, object) + 3 per tile (rank|class, and the 8-byte item)
     assert sizes.order_bytes == (512 + 4 * 3 * 32 + 4 * 3 * 16 * 16 * 3) * 4
+    # an odd tile-table length (odd env count x odd tiles per side) gets one pad word: the 8-byte items stay aligned
+    sc.n_env, sc.img = 1, 72
+    assert lib.occ_workspace_query(ctypes.byref(sc), 64, ctypes.byref(sizes)) == 0
+    assert sizes.order_bytes == (512 + 3 * 32 + 3 * 81 + 1 + 3 * 81 * 2) * 4
+    sc.n_env, sc.img = 4, 128
     sc.img = 100  # not a multiple of the tile size
     assert lib.occ_workspace_query(ctypes.byref(sc), 64, ctypes.byref(sizes)) == 1
     # null pointers are rejected before anything is launched

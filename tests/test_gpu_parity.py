@@ -106,8 +106,8 @@ def test_objects_out_of_view_and_on_the_border():
 
 def test_far_camera_thousands_of_candidates_per_pixel():
     """radius 30: a 20 480-face object covers a handful of pixels, every one of which collects thousands of
-    candidates -> the K-buffer lists fill up (OCC_LIST_CAP = 512 per lane) and are compacted inside the loop of the
-    shipped library, pruning bounds tighten while faces are still arriving."""
+    candidates -> the wave's candidate log fills up (OCC_LOG_CAP = 12 288 entries) and is compacted inside the loop of
+    the shipped library, pruning bounds tighten while faces are still arriving."""
     res = run_parity_case(n_env=2, img=64, seed=14, mesh="mixed", radius=30.0)
     _check(res)
 
@@ -121,10 +121,10 @@ def test_img_256():
     _check(run_parity_case(n_env=1, img=256, seed=8, mesh="teapot"))
 
 
-def test_small_list_capacity_build_forces_inloop_compaction():
-    """Same sources built with OCC_LIST_CAP=104 (< typical candidate counts): every dense pixel goes through the
-    in-loop keep-the-K-nearest compaction.  Runs in a child process because the library is chosen at load time."""
-    lib = os.path.join(ROOT, "occlusionenv_amd", "libocc_hip_cap104.so")
+def test_small_log_build_forces_inloop_compaction():
+    """Same sources built with the smallest legal candidate log (OCC_LOG_CAP = 10 368 entries): dense tiles go through
+    the in-loop keep-the-K-nearest compaction.  Runs in a child process because the library is chosen at load time."""
+    lib = os.path.join(ROOT, "occlusionenv_amd", "libocc_hip_smalllog.so")
     assert os.path.exists(lib), "run __graft_entry__.build() first"
     code = ("import json,sys; sys.path.insert(0, %r); from tests.parity_utils import run_parity_case; "
             "print('RES'+json.dumps(run_parity_case(n_env=2, img=64, seed=2, mesh='synthetic')))" % ROOT)
@@ -137,8 +137,11 @@ def test_small_list_capacity_build_forces_inloop_compaction():
 
 def test_multi_step_trajectory_matches_oracle():
     """State carried across steps (el/az accumulation, fullReward hand-over, environment.py:354-392): five steps of a
-    gradient-ascent trajectory (demo.py:80-114) driven by the oracle's gradients, same actions on both sides."""
-    from tests.parity_utils import make_case, oracle_env
+    gradient-ascent trajectory (demo.py:80-114) driven by the oracle's gradients, same actions on both sides.  The
+    action gradient of EVERY step goes through the one criterion of parity_utils (1e-4 relative against the f32
+    oracle, else the f64 oracle - stepped along the same trajectory - arbitrates with the fp32 noise floor)."""
+    from oracle import p3d_restate as O
+    from tests.parity_utils import engine_grad_parts, grad_check, gradient_mass, make_case, oracle_env
     from occlusionenv_amd.engine import OcclusionEngine
 
     img, T, lr = 64, 5, 0.05
@@ -148,6 +151,9 @@ def test_multi_step_trajectory_matches_oracle():
     eng.reset_render(None, 4.0, case["az"], 0.0)
     env = oracle_env(case, 0, img)
     env.reset(azimuth=float(case["az"][0]))
+    env64 = O.OracleEnv([(v.double(), f) for v, f in env.objs], img, dtype=torch.float64)
+    env64.reset(azimuth=float(case["az"][0]))
+    ones = torch.ones(img, img)
     a_o = torch.zeros(2)
     for t in range(T):
         ag = a_o.clone().reshape(1, 2).cuda().requires_grad_(True)
@@ -156,12 +162,26 @@ def test_multi_step_trajectory_matches_oracle():
         ao = a_o.clone().requires_grad_(True)
         obs_o, r_o, d_o, info = env.step(ao)
         r_o.backward()
+        a64 = a_o.clone().double().requires_grad_(True)
+        r64 = env64.step(a64)[1]  # the f64 oracle follows the same actions, whether or not it is consulted
         assert abs(float(r) - float(r_o)) < TOL, (t, float(r), float(r_o))
         assert abs(float(loss) - float(info["full_reward"])) / max(1.0, float(info["full_reward"])) < TOL
-        assert (ag.grad[0].cpu() - ao.grad).norm() / ao.grad.norm().clamp(min=1e-6) < 2e-3
+        assert bool(d[0]) == bool(d_o)
+
+        def g64():
+            r64.backward()
+            return a64.grad
+
+        gc = grad_check(ag.grad[0].cpu(), ao.grad, g64, lambda: gradient_mass(engine_grad_parts(eng), 0, ones))
+        assert gc["ok"], (t, gc)
         assert abs(float(eng.elevation[0]) - float(env.elevation)) < 1e-6 and abs(float(eng.azimuth[0]) - float(env.azimuth)) < 1e-6
         assert torch.allclose(eng.camera_position[0].cpu(), env.camera_position.detach(), atol=1e-5)
         a_o = (a_o + lr * ao.grad).detach()
+
+
+def test_bench_pool_meshes_match_oracle():
+    """The bench workload's own meshes (SyntheticShapeNet(n_models=1024, seed=1234), bench.py), 3 envs, 128x128."""
+    _check(run_parity_case(n_env=3, img=128, seed=31, mesh="benchpool"))
 
 
 @pytest.mark.parametrize("shader", ["hard_phong", "soft_phong"])
@@ -251,33 +271,18 @@ def test_step_through_the_degenerate_camera_pose():
     assert torch.isfinite(a.grad).all() and torch.isfinite(ao.grad).all()
 
 
-_ORDER_SCRIPT = r"""
-import sys, torch
-sys.path.insert(0, sys.argv[1])
-from tests.parity_utils import make_case, run_engine
-case = make_case(48, 321, "mixed", az_range=2.5)
-r = run_engine(case, 128)
-torch.save({k: r[k] for k in ("obs", "alphas", "fs", "loss", "grad", "obj_grad")}, sys.argv[2])
-"""
-
-
-def test_results_do_not_depend_on_the_work_item_order(tmp_path):
+def test_results_do_not_depend_on_the_work_item_order():
     """occ_raster2_kernel takes its tiles heaviest first (OccWorkspace.order; positions inside a cost class depend on
     the order in which the setup blocks reserved them, so the ORDER of items varies from launch to launch): every
-    output must be bit-identical between two launches and against the rect order (OCC_ORDER=0, a fresh process)."""
+    output must be bit-identical between two launches and against the plain rect order (OccWorkspace.order = NULL)."""
     from tests.parity_utils import make_case, run_engine
 
     keys = ("obs", "alphas", "fs", "loss", "grad", "obj_grad")
     runs = []
-    for _ in range(2):
-        r = run_engine(make_case(48, 321, "mixed", az_range=2.5), 128)
+    for cost_order in (True, True, False):
+        r = run_engine(make_case(48, 321, "mixed", az_range=2.5), 128, cost_order=cost_order)
         runs.append({k: r[k] for k in keys})
         del r
     for k in keys:
         assert torch.equal(runs[0][k], runs[1][k]), k
-    out = tmp_path / "rect.pt"
-    env = dict(os.environ, OCC_ORDER="0")
-    subprocess.run([sys.executable, "-c", _ORDER_SCRIPT, ROOT, str(out)], check=True, env=env, timeout=600)
-    rect = torch.load(out)
-    for k in keys:
-        assert torch.equal(runs[0][k], rect[k]), k
+        assert torch.equal(runs[0][k], runs[2][k]), (k, "rect order")

@@ -326,3 +326,16 @@ def test_obs_space_helpers_cover_plain_dict_and_tuple_spaces():
     assert c == buf and c is not buf
     with pytest.raises(AssertionError):
         copy_obs_dict({"img": 1})
+
+
+def test_tie_classifier_bands_are_frozen():
+    """The near-tie classifier is what stands between a real bug and a green parity test: its bands may be
+    tightened, never loosened, without this test being changed on purpose."""
+    from tests import parity_utils as pu
+
+    frozen = dict(TOL=1e-4, TZ_REL=1e-6, TB_REL=1e-4, TPAIR_REL=1e-4, TEDGE=5e-7, TAREA=2e-9, TTEXEL=1e-3,
+                  GRAD_NOISE_ULPS=256.0)
+    for name, bound in frozen.items():
+        assert 0 < getattr(pu, name) <= bound, (name, getattr(pu, name), bound)
+    for img in (64, 128, 256, 512):
+        assert pu.max_tie_pixels(img) <= max(4, int(2e-4 * img * img * 3))
