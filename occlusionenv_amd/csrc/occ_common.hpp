@@ -42,6 +42,21 @@ __device__ __forceinline__ uint32_t ord_class_bound(int cls) {
     return fl == 0 ? 2u : (half ? 2u << fl : 3u << (fl - 1));
 }
 
+// Cross-lane hand-over through LDS inside ONE wave (the raster kernel's workgroup is a single wave64).  The LDS unit
+// executes a wave's operations in issue order, so a lane reading what another lane of the same wave stored earlier in
+// program order needs no hardware wait at all - only the compiler has to keep that program order.  __syncthreads()
+// would also drain every outstanding global load and store (s_waitcnt vmcnt(0)): the candidate-log stores of the round
+// just evaluated and the record loads that are meant to stay in flight.
+__device__ __forceinline__ void wave_lds_sync() {
+#ifdef OCC_AB_SYNCTHREADS  // A/B timing build only: the old full barrier
+    __syncthreads();
+    return;
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);

@@ -34,7 +34,7 @@
 //     contiguously; every entry bumps the LDS histogram of ITS pixel; the pixel's owner lane (lane = pixel) scans its
 //     32 buckets and narrows its window; sweeps keep two groups of four 512-byte loads in flight (a sweep with one
 //     dependent load per iteration is pure memory latency).  Afterwards one more sweep re-accumulates the kept entries
-//     of the overflowing pixels (log-domain product) into the pixel's four accumulator copies by plain
+//     of the overflowing pixels into the pixel's four accumulator copies by plain
 //     read-modify-write, one sub-pass per group of four faces (the tag's sequence number): three LDS float atomics per
 //     entry, colliding on the pixel, cost 0.28 of 2.39 ms; ranking the lanes of a row by pixel with six ballots was
 //     slower still.  When the log fills up (thousands of candidates per pixel: far cameras, dense meshes) the same
@@ -62,7 +62,11 @@ constexpr int kSelDw = (1 << kSelBits) / 2;
 constexpr int kSweepU = 4;     // 64-entry rows of the log per sweep group; two groups are in flight (wider groups /
                                // 16-byte double rows were measured slower: they push the kernel into spilling)
 constexpr int kListCap = 8;    // boundary-bucket entries per pixel that the owner lane resolves itself
-constexpr int kCopies = 4;     // accumulator copies (staged face & 3)
+#ifndef OCC_ACC_COPY_BITS
+#define OCC_ACC_COPY_BITS 2
+#endif
+constexpr int kCopyBits = OCC_ACC_COPY_BITS;  // accumulator copies = 1 << kCopyBits, chosen by (face sequence number & (kCopies - 1))
+constexpr int kCopies = 1 << kCopyBits;
 constexpr int kAccStride = 65; // accumulator slots per copy: one per pixel, +1 so that the copies of a pixel differ mod 16 (acc_slot)
 
 constexpr uint32_t kNoEntry = 0xFFFFFFFFu;  // tag of a slot past the end of the log (a tag is pixel | face sequence number << 6)
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
     uint32_t* const s_take = s_selbase + 128;
     uint32_t* const s_lcnt = s_selbase + 192;   // boundary-list fill counts (final selection) ...
     uint32_t* const s_kmax2 = s_selbase + 192;  // ... or the kept entries' largest key (in-loop compaction): never both
-    // re-accumulated (sum log2(1 - p), sum g_el, sum g_az, count) of the pixels that went through selection
+    // re-accumulated (prod (1 - p), sum g_el, sum g_az, count) of the pixels that went through selection
     float4* const s_acc2 = reinterpret_cast<float4*>(s_selbase + 256);
     // two hit lists: while one batch is evaluated the next one is already scanned and its records are in flight
     __shared__ int s_hit[2 * kStg2];               // record index of every staged face
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
         const float4* __restrict__ recs4 = reinterpret_cast<const float4*>(P.ws.rec + span.base * OCC_REC_STRIDE);
         const uint4* __restrict__ scan = reinterpret_cast<const uint4*>(P.ws.scan) + span.base;
 
-        __syncthreads();  // the previous item's readers of the LDS state are done
+        wave_lds_sync();  // the previous item's readers of the LDS state are done
         // [P3D] pixel centre of the pixel this lane owns, in NDC, +X left, +Y up: same expression as the
         // oracle; a pair lane fetches the centre of ITS pixel from the owning lanes with two cross-lane reads
         const float own_xf = -1.0f + (2.0f * (float)(S - 1 - xi) + 1.0f) / fS;
@@ -253,10 +257,29 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
         };
         // this lane's pixel: candidates held and their largest key (four copies folded)
         auto own_count = [&]() {
-            return (int)(s_acc[myslot].w + s_acc[1 * kAccStride + myslot].w + s_acc[2 * kAccStride + myslot].w + s_acc[3 * kAccStride + myslot].w);
+            float c = 0.f;  // small integers: any summation order is exact
+#pragma unroll
+            for (int cpy = 0; cpy < kCopies; ++cpy) c += s_acc[cpy * kAccStride + myslot].w;
+            return (int)c;
         };
         auto own_kmax = [&]() {
-            return akm_dec(max(max((uint32_t)s_akm[myslot], (uint32_t)s_akm[1 * kAccStride + myslot]), max((uint32_t)s_akm[2 * kAccStride + myslot], (uint32_t)s_akm[3 * kAccStride + myslot])));
+            uint32_t m = 0u;
+#pragma unroll
+            for (int cpy = 0; cpy < kCopies; ++cpy) m = max(m, (uint32_t)s_akm[cpy * kAccStride + myslot]);
+            return akm_dec(m);
+        };
+        // this lane's pixel: the copies folded in a FIXED order (pairwise: (0 * 1) * (2 * 3)) - reproducible results
+        auto own_fold = [&]() {
+            float4 a[kCopies];
+#pragma unroll
+            for (int cpy = 0; cpy < kCopies; ++cpy) a[cpy] = s_acc[cpy * kAccStride + myslot];
+#pragma unroll
+            for (int st = 1; st < kCopies; st <<= 1) {
+#pragma unroll
+                for (int cpy = 0; cpy + st < kCopies; cpy += 2 * st)
+                    a[cpy] = make_float4(a[cpy].x * a[cpy + st].x, a[cpy].y + a[cpy + st].y, a[cpy].z + a[cpy + st].z, a[cpy].w + a[cpy + st].w);
+            }
+            return a[0];
         };
 
         // ---- exact top-K over the log for every pixel holding more than K entries ---------------------------
@@ -264,7 +287,8 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
         // this lane's pixel was one of them.  COMPACT also rewrites the log so that it holds exactly the entries still
         // accounted for, and folds the selected sums back into the accumulator copies.
         auto select_topk = [&](const bool compact) __attribute__((always_inline)) -> bool {
-            __syncthreads();
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every log entry written so far is in memory before it is swept
+            wave_lds_sync();
             uint32_t* hist = reinterpret_cast<uint32_t*>(s_pool);  // 64 pixels x kSelDw dwords (u16 buckets)
             const int cnt = own_count();
             const bool ovf = cnt > K;
@@ -298,7 +322,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             while (__ballot(!done)) {
 #pragma unroll
                 for (int i = 0; i < kSelDw; i += 4) reinterpret_cast<uint4*>(hist + lane * kSelDw)[i >> 2] = make_uint4(0u, 0u, 0u, 0u);
-                __syncthreads();
+                wave_lds_sync();
                 auto bump = [&](const uint2 (&kt)[kSweepU]) __attribute__((always_inline)) {
 #pragma unroll
                     for (int u = 0; u < kSweepU; ++u) {
@@ -322,7 +346,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                         bump(kb);
                     }
                 }
-                __syncthreads();
+                wave_lds_sync();
                 OCC_T(11);  // selection: histogram sweeps
                 if (!done) {
                     int cum = 0, bstar = (1 << kSelBits) - 1, mstar = 0, cumb = 0;
@@ -352,20 +376,20 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     }
                     s_sel[lane] = make_uint2(L, done ? 255u : (uint32_t)sh);
                 }
-                __syncthreads();
+                wave_lds_sync();
                 OCC_T(12);  // selection: bucket scans
             }
             // final window of an overflowing pixel: keys < L are kept, of the bucket [L, L + 2^sh) `need` more
             s_sel[lane] = make_uint2(L, ovf ? (uint32_t)sh | ((uint32_t)mode << 8) : 255u);
             s_take[lane] = mode == kAll ? 0x7FFFFFFFu : (uint32_t)max(need, 0);
             s_lcnt[lane] = 0u;  // kList: entries collected so far / compaction: largest kept key
-            s_acc2[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ovf) {  // its accumulated sums are void: the copies now collect the log-domain sums of the kept entries
+            s_acc2[lane] = make_float4(1.f, 0.f, 0.f, 0.f);
+            if (ovf) {  // its accumulated state is void: the copies now collect the kept entries (product, sums, count)
 #pragma unroll
-                for (int cpy = 0; cpy < kCopies; ++cpy) s_acc[cpy * kAccStride + myslot] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int cpy = 0; cpy < kCopies; ++cpy) s_acc[cpy * kAccStride + myslot] = make_float4(1.f, 0.f, 0.f, 0.f);
             }
             uint2* blist = reinterpret_cast<uint2*>(s_pool);  // kList: (key, log index) x kListCap per pixel (histograms are done)
-            __syncthreads();
+            wave_lds_sync();
             int wr = 0;
             auto settle = [&](const int e0, const uint2 (&kt)[kSweepU]) __attribute__((always_inline)) {
                 uint32_t keepm = 0u, readdm = 0u;  // per-row decisions of this lane, bit u
@@ -406,24 +430,23 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #pragma unroll
                 for (int u = 0; u < kSweepU; ++u) {
                     {
-                        // Re-accumulate the kept entries - product of the (1 - p_k) in the log domain: exp2(sum log2);
-                        // log2(0) = -inf -> 0 - into the pixel's four accumulator copies by PLAIN read-modify-write,
-                        // as the evaluation rounds do: the tag carries the face's sequence number, faces 4 g .. 4 g + 3
+                        // Re-accumulate the kept entries - the product of the (1 - p_k) and the tangent sums, exactly as
+                        // the evaluation rounds do - into the pixel's four accumulator copies by PLAIN read-modify-write:
+                        // the tag carries the face's sequence number, faces 4 g .. 4 g + 3
                         // use copies 0..3, and one sub-pass applies the lanes of one group g, so no two lanes of an
                         // instruction share an address (three LDS float atomics per entry, colliding on the pixel,
                         // cost 0.28 of the launch's 2.39 ms).
                         const bool act = (readdm >> u) & 1u;
                         const uint32_t tag = kt[u].y;
-                        const uint32_t grp = tag >> 8;
-                        const int slot = acc_slot((int)((tag >> 6) & 3u), (int)(tag & 63u));
-                        const float lq = __builtin_amdgcn_logf(pv[u].q);
+                        const uint32_t grp = tag >> (6 + kCopyBits);
+                        const int slot = acc_slot((int)((tag >> 6) & (uint32_t)(kCopies - 1)), (int)(tag & 63u));
                         unsigned long long rem = __ballot(act);
                         while (rem) {
                             const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)grp, __ffsll(rem) - 1);
                             const bool mine = act && grp == g0;
                             if (mine) {
                                 float4 a = s_acc[slot];
-                                a.x += lq;
+                                a.x *= pv[u].q;
                                 if (GRAD) {
                                     a.y += pv[u].ge;
                                     a.z += pv[u].ga;
@@ -463,13 +486,8 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     settle(e0 + kGroup, kb);
                 }
             }
-            __syncthreads();
-            if (ovf) {  // fold the four copies in a fixed order
-                const float4 a0 = s_acc[myslot], a1 = s_acc[kAccStride + myslot], a2 = s_acc[2 * kAccStride + myslot],
-                             a3 = s_acc[3 * kAccStride + myslot];
-                s_acc2[lane] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
-                                           (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
-            }
+            wave_lds_sync();
+            if (ovf) s_acc2[lane] = own_fold();
             OCC_T(13);  // selection: final sweep
             if (!compact && __ballot(mode == kList)) {
                 // the owner lane picks the `need` nearest of its <= kListCap boundary entries by (key, log index) and
@@ -495,7 +513,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #pragma unroll
                 for (int i = 0; i < kListCap; ++i) {
                     if ((takem >> i) & 1u) {
-                        sl += __builtin_amdgcn_logf(pv[i].q);
+                        sl *= pv[i].q;
                         se += pv[i].ge;
                         sa += pv[i].ga;
                     }
@@ -507,7 +525,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 nlog = wr;
                 if (ovf) {  // the selected sums become the pixel's accumulated state (copy 0; the others empty)
                     const float4 a2 = s_acc2[lane];
-                    s_acc[myslot] = make_float4(__builtin_amdgcn_exp2f(a2.x), a2.y, a2.z, a2.w);
+                    s_acc[myslot] = a2;
                     s_akm[myslot] = akm_enc(s_kmax2[lane]);
 #pragma unroll
                     for (int cpy = 1; cpy < kCopies; ++cpy) {
@@ -516,7 +534,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     }
                 }
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the rewritten log is in place before it grows again
-                __syncthreads();
+                wave_lds_sync();
             }
             return ovf;
         };
@@ -613,7 +631,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
         // batch is scanned and its record loads are issued, to fly during this batch's evaluation rounds.
         auto process_batch = [&]() __attribute__((always_inline)) -> int {
             OCC_T(2);  // scan (chunk boxes, rows, hit lists)
-            __syncthreads();
+            wave_lds_sync();
             // pixels of this lane's face inside the tile: pair count, prefix sum over the staged faces
             int c = 0, cx0 = 0, cy0 = 0, cw = 1;
             if (lane < nst) {
@@ -660,7 +678,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 stage_commit(rstage, nst);
-                __syncthreads();
+                wave_lds_sync();
                 __builtin_amdgcn_sched_barrier(0);
                 OCC_T(4);  // pair map + record commit
             }
@@ -680,7 +698,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     // the histograms lived on top of the records and the pair map: put both back
                     stage_records();
                     mark_pairs();
-                    __syncthreads();
+                    wave_lds_sync();
                     OCC_T(7);  // in-loop compaction
                 }
                 int fbase = 0;  // face of the pair just before this round
@@ -763,9 +781,9 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                             // accumulate: plain read-modify-write in sub-passes of four consecutive staged faces
                             const int f_first = __builtin_amdgcn_readfirstlane(f);
                             const int f_last = __builtin_amdgcn_readlane(f, nlive - 1);
-                            const int slot = acc_slot(f & 3, pix);
-                            const int grp = (f - f_first) >> 2;
-                            const int nsub = ((f_last - f_first) >> 2) + 1;
+                            const int slot = acc_slot(f & (kCopies - 1), pix);
+                            const int grp = (f - f_first) >> kCopyBits;
+                            const int nsub = ((f_last - f_first) >> kCopyBits) + 1;
                             for (int sp = 0; sp < nsub; ++sp) {
                                 if (acc && grp == sp) {
                                     float4 a = s_acc[slot];
@@ -787,7 +805,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     }
                 }
             }
-            __syncthreads();
+            wave_lds_sync();
             OCC_T(5);  // evaluation rounds
             // Front-to-back pruning (SURVEY A.4 keeps the K smallest depths): once a pixel holds >= K candidates its
             // largest stored key bounds its K-th nearest from above, later candidates at or beyond it are dropped
@@ -827,7 +845,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
         // ---- per-pixel results (lane = pixel) ---------------------------------------------------------------------
         const size_t opix = ((size_t)eo * S + yi) * S + xi;
         if (SOFT) {
-            __syncthreads();
+            wave_lds_sync();
             const bool ovf = own_count() > K;
 #ifdef OCC_DBG_STATS
             {
@@ -853,14 +871,14 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             float prod, sge, sga;
             if (selected) {
                 const float4 a2 = s_acc2[lane];
-                prod = __builtin_amdgcn_exp2f(a2.x);
+                prod = a2.x;
                 sge = a2.y;
                 sga = a2.z;
-            } else {  // fold the four copies in a fixed order
-                const float4 a0 = s_acc[myslot], a1 = s_acc[1 * kAccStride + myslot], a2 = s_acc[2 * kAccStride + myslot], a3 = s_acc[3 * kAccStride + myslot];
-                prod = (a0.x * a1.x) * (a2.x * a3.x);
-                sge = (a0.y + a1.y) + (a2.y + a3.y);
-                sga = (a0.z + a1.z) + (a2.z + a3.z);
+            } else {
+                const float4 a = own_fold();
+                prod = a.x;
+                sge = a.y;
+                sga = a.z;
             }
             P.ws.obj_alpha[opix] = 1.0f - prod;
             if (GRAD) {
