@@ -605,3 +605,36 @@ def test_work_item_order_is_a_cost_sorted_permutation_of_all_tiles(mesh, S):
         xl, yl, xh, yh = bb[:, 0] & 0xFFFF, bb[:, 0] >> 16, bb[:, 1] & 0xFFFF, bb[:, 1] >> 16
         touching = int(np.count_nonzero((xl <= tx * 8 + 7) & (xh >= tx * 8) & (yl <= ty * 8 + 7) & (yh >= ty * 8)))
         assert touching < bound(int(cls[k])), (eo, tx, ty, touching, int(cls[k]))
+
+
+def test_env_on_a_shapenetcore_directory(tmp_path):
+    """trainRL.py:66-75 with the directory reader instead of PyTorch3D's ShapeNetCore: OcclusionEnv(dataset) resets,
+    steps and renders textured models read from <synset>/<model>/models/model_normalized.obj (+ .mtl + image)."""
+    from occlusionenv_amd.shapenet import ShapeNetCoreDir
+    from tests.test_shapenet_dir import _write_model
+    from environment import OcclusionEnv
+    from SubProcVecEnv import SimpleVecEnv
+
+    root = str(tmp_path / "shapenetcore")
+    for k, syn in enumerate(["02691156", "03001627", "04379243"]):
+        for m in range(2):
+            _write_model(root, syn, f"m{k}{m}", scale=0.25 + 0.05 * m)
+    ds = ShapeNetCoreDir(root, version=2)
+    assert len(ds) == 6 and len(ds.synset_dict) == 3
+    env = OcclusionEnv(ds, img_size=64)
+    obs = env.reset()
+    assert obs.shape == (1, 4, 64, 64) and torch.isfinite(obs).all()
+    a = torch.nn.Parameter(torch.tensor([0.3, -0.2], device="cuda"))
+    obs, reward, done, info = env.step(a)
+    reward.backward()
+    assert torch.isfinite(a.grad).all() and torch.isfinite(obs).all()
+    fg = obs[0, 3] > 0
+    assert bool(fg.any())
+    rgb = obs[0, :3][:, fg]
+    # the cubes carry a red Kd material, an image-textured face and grey faces: the observation is not all white/grey
+    assert float((rgb.max(0).values - rgb.min(0).values).max()) > 0.2
+    venv = SimpleVecEnv([lambda: OcclusionEnv(ds, img_size=64) for _ in range(4)])
+    o = venv.reset()
+    assert o.shape == (4, 1, 4, 64, 64)
+    o2, r2, d2, _ = venv.step(torch.zeros(4, 2, device="cuda"))
+    assert o2.shape == (4, 4, 64, 64) and torch.isfinite(r2).all()
