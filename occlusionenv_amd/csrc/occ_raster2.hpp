@@ -675,18 +675,29 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 mark_pairs();
                 // the records of THIS batch were requested a whole batch ago: wait for them here, explicitly, and keep
                 // the compiler from moving the next batch's loads above this wait (it would then wait for those too)
+#ifdef OCC_EXP_LATE_STAGE
+                {
+                    float4 r_[kStageLoads];
+                    stage_issue(r_, boff, nst);
+                    stage_commit(r_, nst);
+                }
+#else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 stage_commit(rstage, nst);
+#endif
                 wave_lds_sync();
                 __builtin_amdgcn_sched_barrier(0);
                 OCC_T(4);  // pair map + record commit
             }
             // scan ahead: the next batch's hit list, its record loads fly while this batch is evaluated
             const int nst_next = fill(boff ^ kStg2);
+#ifndef OCC_EXP_LATE_STAGE
             if (nst_next) stage_issue(rstage, boff ^ kStg2, nst_next);
+#endif
             OCC_T(2);
             {
+#ifndef OCC_EXP_NO_COMPACT  // register-pressure experiment only
                 if (SOFT && nlog + ptot > OCC_LOG_CAP) {
                     // rare: the log could fill up inside this batch -> keep every overflowing pixel's K nearest,
                     // compact the log, go on with tighter bounds
@@ -701,6 +712,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     wave_lds_sync();
                     OCC_T(7);  // in-loop compaction
                 }
+#endif
                 int fbase = 0;  // face of the pair just before this round
 #ifdef OCC_DBG2_NO_EVAL  // timing experiment only
                 if (ptot > 0) fbase = -1;
@@ -832,7 +844,9 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
         };
 
         nst = fill(0);
+#ifndef OCC_EXP_LATE_STAGE
         if (nst) stage_issue(rstage, 0, nst);
+#endif
         while (nst) {
             const int nst_next = process_batch();
             boff ^= kStg2;

@@ -121,22 +121,27 @@ class BatchedPPO:
         returns = (returns - returns.mean()) / (returns.std() + 1e-7)
         feats, actions = feats.reshape(-1, 256), actions.reshape(-1, 2)
         old_lp, returns = old_lp.reshape(-1), returns.reshape(-1)
-        first = last = None
+        losses, vlosses = [], []
         for _ in range(self.K_epochs):
             lp, value, ent = self.policy.evaluate(feats, actions)
             ratios = torch.exp(lp - old_lp)
             adv = returns - value.detach()
             surr1 = ratios * adv
             surr2 = torch.clamp(ratios, 1 - self.eps_clip, 1 + self.eps_clip) * adv
-            loss = (-torch.min(surr1, surr2) + 0.5 * torch.mean((value - returns) ** 2) - 0.01 * ent).mean()
+            vloss = torch.mean((value - returns) ** 2)
+            loss = (-torch.min(surr1, surr2) + 0.5 * vloss - 0.01 * ent).mean()
             self.optimizer.zero_grad()
             loss.backward()
             self.optimizer.step()
-            last = float(loss.detach())
-            first = last if first is None else first
+            losses.append(loss.detach())
+            vlosses.append(vloss.detach())
+        # one host sync for the whole update (the reference syncs nowhere inside its epoch loop either, PPO.py:196-217)
+        losses, vlosses = torch.stack(losses).cpu(), torch.stack(vlosses).cpu()
         self.policy_old.load_state_dict(self.policy.state_dict())
         self.records = []
-        return dict(loss_first=first, loss_last=last, samples=int(feats.shape[0]))
+        # NB the total is not monotone: the advantages (returns - value) are re-evaluated with the improving critic
+        return dict(loss_first=float(losses[0]), loss_last=float(losses[-1]), value_loss_first=float(vlosses[0]),
+                    value_loss_last=float(vlosses[-1]), samples=int(feats.shape[0]))
 
 
 def train_rollouts(venv, agent: BatchedPPO, n_updates: int = 1, T: int = 50, with_action_grad: bool = False,

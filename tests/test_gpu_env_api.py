@@ -306,7 +306,9 @@ def test_config5_per_rank_ppo_rollout_and_update():
     assert len(stats) == 1 and stats[0]["samples"] == T * N
     st = stats[0]
     assert np.isfinite(st["loss_first"]) and np.isfinite(st["loss_last"]) and np.isfinite(st["mean_reward"])
-    assert st["loss_last"] < st["loss_first"]  # 80 epochs on the heads reduce the clipped-surrogate + value loss
+    # 80 Adam epochs on the value head shrink its regression loss on the (fixed) normalised returns; the TOTAL is not
+    # monotone, because the advantages returns - value are re-evaluated with the improving critic every epoch
+    assert np.isfinite(st["value_loss_last"]) and st["value_loss_last"] < st["value_loss_first"]
     g = torch.stack(grads)
     assert g.shape == (T, N, 2) and torch.isfinite(g).all() and float(g.abs().max()) > 0.0
     venv._drain()
