@@ -42,6 +42,14 @@ __device__ __forceinline__ uint32_t ord_class_bound(int cls) {
     return fl == 0 ? 2u : (half ? 2u << fl : 3u << (fl - 1));
 }
 
+// a * b for operands below 2^24 as ONE full-rate instruction.  Opaque on purpose: left to itself hipcc folds the
+// surrounding subtraction into a multiply by a negative constant, which needs the quarter-rate v_mul_lo_u32.
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Cross-lane hand-over through LDS inside ONE wave (the raster kernel's workgroup is a single wave64).  The LDS unit
 // executes a wave's operations in issue order, so a lane reading what another lane of the same wave stored earlier in
 // program order needs no hardware wait at all - only the compiler has to keep that program order.  __syncthreads()

@@ -13,26 +13,23 @@ struct Cand {
     float ge, ga; // p * d(d)/d el, p * d(d)/d az
 };
 
-// Evaluate one projected face (wave-uniform record r -> SGPRs) at this lane's pixel centre.
+// Evaluate one projected face at this lane's pixel centre.
 // Restates [P3D] CheckPixelInsideFace and, for GRAD, the dists part of
 // RasterizeMeshesBackward (A.5) pushed forward along the two vertex tangents.
-// One staged record pulled out of LDS with 16-byte broadcast reads (every lane reads the same address).
-// Slot map as in occ_constants.h:
-//   a = x0 y0 z0 x1 | b = y1 z1 x2 y2 | c = z2 id flags inv_area | d = bbox | e = il01 il02 il12 - |
-//   g, h, i = tangents of v0, v1, v2 (dx/del dy/del dx/daz dy/daz)      -- 8 parts = 128 bytes = one cache line
-// The eight float4 parts travel as SSA values (by value, never through a struct in memory: a select between two
-// loads of one stack object gets folded into a dynamically indexed load, which pins the object in scratch).
-#define OCC_REC_PARAMS float4 ra, float4 rb, float4 rc, float4 rd, float4 re, float4 rg, float4 rh, float4 ri
-#define OCC_REC_LOAD(src, PARTS)                                                                   \
-    (src)[0], (src)[1], (src)[2], (src)[3], ((PARTS) > 4 ? (src)[4] : make_float4(0, 0, 0, 0)),      \
-        ((PARTS) > 5 ? (src)[5] : make_float4(0, 0, 0, 0)), ((PARTS) > 5 ? (src)[6] : make_float4(0, 0, 0, 0)), \
-        ((PARTS) > 5 ? (src)[7] : make_float4(0, 0, 0, 0))
+// Record slot map (occ_constants.h):
+//   a = x0 y0 z0 x1 | b = y1 z1 x2 y2 | c = z2 id flags inv_area | d = bbox | e = il01 il02 il12 spec |
+//   parts 5, 6, 7 = tangents of v0, v1, v2 (dx/del dy/del dx/daz dy/daz)      -- 8 parts = 128 bytes = one cache line
+// The first five parts travel as SSA values (by value, never through a struct in memory: a select between two loads of
+// one stack object gets folded into a dynamically indexed load, which pins the object in scratch).  The tangents are
+// FETCHED once the closest edge is known - tan(v) returns the tangent part of vertex v (0, 1, 2; per lane) - two
+// 16-byte reads at a computed address instead of three up front and sixteen selects among their components.
+#define OCC_REC_PARAMS float4 ra, float4 rb, float4 rc, float4 rd, float4 re
+#define OCC_REC_LOAD(src, PARTS) (src)[0], (src)[1], (src)[2], (src)[3], ((PARTS) > 4 ? (src)[4] : make_float4(0, 0, 0, 0))
 
-// Evaluate one projected face at this lane's pixel centre.  EARLY: lanes outside the face's bbox leave at once (the
-// block kernel evaluates a face at all 16 pixels of a block, most of them outside); the pair kernel only visits
-// pixels of the face's pixel bbox, where a divergent early exit costs more than it saves: branch-free, masked at the end.
-template <bool SOFT, bool GRAD, bool EARLY = true>
-__device__ __forceinline__ void eval_face(OCC_REC_PARAMS, float xf, float yf, Cand& c) {
+// Branch-free (the pair kernel only visits pixels of the face's pixel bbox, where a divergent early exit costs more
+// than it saves): everything is evaluated, candidates are masked at the end.
+template <bool SOFT, bool GRAD, class TanFn>
+__device__ __forceinline__ void eval_face(OCC_REC_PARAMS, float xf, float yf, Cand& c, TanFn tan) {
     c.cand = false;
     c.inside = false;
     c.z = c.zh = c.ad = 0.f;
@@ -40,7 +37,6 @@ __device__ __forceinline__ void eval_face(OCC_REC_PARAMS, float xf, float yf, Ca
     c.ge = c.ga = 0.f;
     c.amin = 0;
     const bool inb = (rd.x <= xf) && (xf <= rd.y) && (rd.z <= yf) && (yf <= rd.w);
-    if (EARLY && !inb) return;
     const float x0 = ra.x, y0 = ra.y, z0 = ra.z;
     const float x1 = ra.w, y1 = rb.x, z1 = rb.y;
     const float x2 = rb.z, y2 = rb.w, z2 = rc.x;
@@ -106,13 +102,10 @@ __device__ __forceinline__ void eval_face(OCC_REC_PARAMS, float xf, float yf, Ca
         const float pax = s12 ? dx1 : dx0, pay = s12 ? dy1 : dy0;
         const float tb = clamp01(dotv * ile);
         const float gx = 2.0f * (tb * bax - pax), gy = 2.0f * (tb * bay - pay);  // 2 (proj - p)
-        // tangent of the projected point: (1-t) a' + t b'
-        const float a_xe = s12 ? rh.x : rg.x, a_ye = s12 ? rh.y : rg.y;
-        const float a_xa = s12 ? rh.z : rg.z, a_ya = s12 ? rh.w : rg.w;
-        const float b_xe = s01 ? rh.x : ri.x, b_ye = s01 ? rh.y : ri.y;
-        const float b_xa = s01 ? rh.z : ri.z, b_ya = s01 ? rh.w : ri.w;
-        const float mxe = a_xe + tb * (b_xe - a_xe), mye = a_ye + tb * (b_ye - a_ye);
-        const float mxa = a_xa + tb * (b_xa - a_xa), mya = a_ya + tb * (b_ya - a_ya);
+        // tangent of the projected point: (1-t) a' + t b'; a = v1 for edge (v1,v2) else v0, b = v1 for edge (v0,v1) else v2
+        const float4 ta = tan(s12 ? 1 : 0), tb4 = tan(s01 ? 1 : 2);
+        const float mxe = ta.x + tb * (tb4.x - ta.x), mye = ta.y + tb * (tb4.y - ta.y);
+        const float mxa = ta.z + tb * (tb4.z - ta.z), mya = ta.w + tb * (tb4.w - ta.w);
         const float any = (s01 || s02 || s12) ? 1.0f : 0.0f;
         const float sp = (inside ? -p : p) * any;
         c.ge = sp * (gx * mxe + gy * mye);

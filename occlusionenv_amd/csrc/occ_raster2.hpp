@@ -59,7 +59,10 @@ constexpr int kStgPad = 33;    // LDS stride (float4) between the parts of the s
 constexpr int kPairCap = 2048; // pairs per batch at most (kStg2 faces x 64 pixels): one byte each in the pair map
 constexpr int kSelBits = 5;    // radix-select digit: 32 u16 buckets = 16 dwords per pixel (4 KB, aliasing records + descriptors)
 constexpr int kSelDw = (1 << kSelBits) / 2;
-constexpr int kSweepU = 4;     // 64-entry rows of the log per sweep group; two groups are in flight (wider groups /
+#ifndef OCC_SWEEP_U
+#define OCC_SWEEP_U 4
+#endif
+constexpr int kSweepU = OCC_SWEEP_U;     // 64-entry rows of the log per sweep group; two groups are in flight (wider groups /
                                // 16-byte double rows were measured slower: they push the kernel into spilling)
 constexpr int kListCap = 8;    // boundary-bucket entries per pixel that the owner lane resolves itself
 #ifndef OCC_ACC_COPY_BITS
@@ -83,7 +86,8 @@ struct WaveLog {
 // the rows of a face's footprint and the four copies of one pixel (four faces evaluated side by side) land on
 // different residues.
 __device__ __forceinline__ int acc_slot(int cpy, int pix) {
-    return cpy * kAccStride + (pix & 56) + ((pix + 3 * (pix >> 4)) & 7);
+    const int r2 = pix >> 4;  // the column rotates by 3 every second row (shifts and adds: no 64-bit mad)
+    return (int)__umul24((uint32_t)cpy, (uint32_t)kAccStride) + (pix & 56) + ((pix + r2 + (r2 << 1)) & 7);
 }
 // Largest stored key of a (copy, pixel) as an upper bound in 16 bits: the key's high half + 1.  Only ever used as a bound
 // from above (a looser bound prunes a little less, never wrongly); 0 = nothing stored.
@@ -220,11 +224,11 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
         ciptr rect = as_const(P.ws.objrect + eo * 4);  // in OCC_BLOCK (4-pixel) units; tiles are 2 x 2 blocks
         const int tx0 = rect[0] >> 1, ty0 = rect[1] >> 1, tw = (rect[2] >> 1) - tx0 + 1;
         const int x0t = (tx0 + local % tw) * kT2, y0t = (ty0 + local / tw) * kT2;
-        if (x0t < 0 || y0t < 0 || x0t + kT2 > S || y0t + kT2 > S) continue;  // never true for a sane rect
+        if (!OCC_BOUND(!(x0t < 0 || y0t < 0 || x0t + kT2 > S || y0t + kT2 > S), 46, eo, local)) continue;  // never true for a sane rect
         const int xi = x0t + (lane & 7), yi = y0t + (lane >> 3);  // the pixel this lane OWNS (lane = pixel)
         const int n = as_const(P.ws.nrec + eo)[0];
         const RecSpan span = rec_span(P.ws, cap, eo);
-        if (n < 0 || n > span.cap) continue;
+        if (!OCC_BOUND(!(n < 0 || n > span.cap), 47, n, eo)) continue;
         OCC_STAT(0, 1);  // work items
         const float4* __restrict__ recs4 = reinterpret_cast<const float4*>(P.ws.rec + span.base * OCC_REC_STRIDE);
         const uint4* __restrict__ scan = reinterpret_cast<const uint4*>(P.ws.scan) + span.base;
@@ -289,6 +293,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
         auto select_topk = [&](const bool compact) __attribute__((always_inline)) -> bool {
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every log entry written so far is in memory before it is swept
             wave_lds_sync();
+            (void)OCC_BOUND(nlog >= 0 && nlog <= OCC_LOG_CAP, 44, nlog, compact);
             uint32_t* hist = reinterpret_cast<uint32_t*>(s_pool);  // 64 pixels x kSelDw dwords (u16 buckets)
             const int cnt = own_count();
             const bool ovf = cnt > K;
@@ -610,7 +615,9 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #pragma unroll
             for (int i = 0; i < kStageLoads; ++i) {
                 const int idx = lane + 64 * i, k = idx >> 3, part = idx & 7;
-                r[i] = (idx < cntf * kRecParts && part < kParts) ? recs4[(size_t)s_hit[boff + k] * kRecParts + part] : make_float4(0, 0, 0, 0);
+                const bool on = idx < cntf * kRecParts && part < kParts;
+                const int hj = on ? s_hit[boff + k] : 0;
+                r[i] = (on && OCC_BOUND(hj >= 0 && hj < n, 42, hj, n)) ? recs4[(size_t)hj * kRecParts + part] : make_float4(0, 0, 0, 0);
             }
         };
         auto stage_commit = [&](const float4 (&r)[kStageLoads], const int cntf) __attribute__((always_inline)) {
@@ -726,30 +733,34 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     fbase += __popcll(mk);
                     const uint2 fg = s_box[boff + f];
                     const uint32_t jj = live ? (uint32_t)(p0 + lane) - fg.x : 0u;
-                    const uint32_t wq = (jj * (fg.y >> 16)) >> 15;  // jj / width (exact for jj < 64, width <= 8)
-                    const uint32_t px_ = (fg.y & 7u) + (jj - wq * (((fg.y >> 6) & 7u) + 1u)), py_ = ((fg.y >> 3) & 7u) + wq;
+                    // jj / width (exact for jj < 64, width <= 8); 24-bit multiplies: full rate (v_mul_lo_u32 is quarter rate)
+                    const uint32_t wq = mul24(jj, fg.y >> 16) >> 15;
+                    const uint32_t px_ = (fg.y & 7u) + (jj - mul24(wq, ((fg.y >> 6) & 7u) + 1u)), py_ = ((fg.y >> 3) & 7u) + wq;
                     const uint32_t d = (py_ << 3) | px_;
                     const int pix = (int)d;
+                    (void)OCC_BOUND(f >= 0 && f < kStg2 && d < 64u, 43, f, d);
                     const int j = s_hit[boff + f];
                     const float xf = __shfl(own_xf, (int)(d & 7u), 64), yf = __shfl(own_yf, (int)(d & 56u), 64);
                     const float4* rs = &s_rec[f];
                     Cand c1;
-                    eval_face<SOFT, GRAD, false>(rs[0], rs[kStgPad], rs[2 * kStgPad], rs[3 * kStgPad],
-                                                 kParts > 4 ? rs[4 * kStgPad] : make_float4(0, 0, 0, 0),
-                                                 kParts > 5 ? rs[5 * kStgPad] : make_float4(0, 0, 0, 0),
-                                                 kParts > 5 ? rs[6 * kStgPad] : make_float4(0, 0, 0, 0),
-                                                 kParts > 5 ? rs[7 * kStgPad] : make_float4(0, 0, 0, 0), xf, yf, c1);
+                    eval_face<SOFT, GRAD>(rs[0], rs[kStgPad], rs[2 * kStgPad], rs[3 * kStgPad],
+                                          kParts > 4 ? rs[4 * kStgPad] : make_float4(0, 0, 0, 0), xf, yf, c1,
+                                          [&](int v) { return rs[(5 + v) * kStgPad]; });
                     const int flags = live ? __float_as_int(rs[2 * kStgPad].z) : 0;
                     // Clipped quad split in two: only one half may enter a pixel's list.  Both halves'
                     // lanes look at both halves; the SECOND half's lane emits the winner when both are candidates,
                     // a half whose partner is no candidate at this pixel emits itself.  (A partner that the pruning
                     // bounds kept out of the batch has no lane: it lies beyond every pixel's K nearest anyway.)
+#ifdef OCC_EXP_NO_PAIR  // instruction-count experiment only
+                    if (false) {
+#else
                     if (__ballot(flags & (FLAG_PAIR_FIRST | FLAG_PAIR_SECOND))) {
+#endif
                         const bool is_first = (flags & FLAG_PAIR_FIRST) != 0, is_second = (flags & FLAG_PAIR_SECOND) != 0;
                         if ((is_first && j + 1 < n) || (is_second && j >= 1)) {
                             const float4* r1 = recs4 + (size_t)(is_first ? j + 1 : j - 1) * kRecParts;
                             Cand cp;
-                            eval_face<SOFT, GRAD, false>(OCC_REC_LOAD(r1, kParts), xf, yf, cp);
+                            eval_face<SOFT, GRAD>(OCC_REC_LOAD(r1, kParts), xf, yf, cp, [&](int v) { return r1[5 + v]; });
                             if (is_first) {
                                 if (cp.cand) c1.cand = false;  // the second half's lane decides
                             } else if (cp.cand && c1.cand) {
@@ -783,9 +794,13 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                         if (m) {
 #ifndef OCC_DBG2_NO_LOG  // timing experiment only
                             if (acc && !nolog) {
-                                const int e = nlog + lane_rank(m);
-                                lg.kt[e] = make_uint2(key, (uint32_t)pix | (uint32_t)(fseq_base + f) << 6);
-                                lg.pay[e] = LogPay{c1.q, c1.ge, c1.ga};
+                                // 32-bit byte offsets from the wave-uniform bases (e < OCC_LOG_CAP): no 64-bit mad per lane
+                                const uint32_t e = (uint32_t)(nlog + lane_rank(m));
+                                if (OCC_BOUND(e < (uint32_t)OCC_LOG_CAP, 41, e, nlog)) {
+                                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(lg.kt) + (e << 3)) =
+                                        make_uint2(key, (uint32_t)pix | (uint32_t)(fseq_base + f) << 6);
+                                    *reinterpret_cast<LogPay*>(reinterpret_cast<char*>(lg.pay) + __umul24(e, 12u)) = LogPay{c1.q, c1.ge, c1.ga};
+                                }
                             }
 #endif
                             if (!nolog) nlog += __popcll(m);
@@ -858,6 +873,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 
         // ---- per-pixel results (lane = pixel) ---------------------------------------------------------------------
         const size_t opix = ((size_t)eo * S + yi) * S + xi;
+        (void)OCC_BOUND(opix < (size_t)P.sc.n_env * 3 * S * S && xi < S && yi < S, 45, eo, yi * S + xi);
         if (SOFT) {
             wave_lds_sync();
             const bool ovf = own_count() > K;

@@ -4,6 +4,6 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p build/ab
 name=$1; shift
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Iinclude -Ioccllusionenv_amd/csrc -Iocclusionenv_amd/csrc "$@" \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 ${SLP:--fno-slp-vectorize} -shared -fPIC -Iinclude -Iocclusionenv_amd/csrc "$@" \
   -o build/ab/libocc_$name.so occlusionenv_amd/csrc/occ_kernels.hip
 echo "built build/ab/libocc_$name.so"
