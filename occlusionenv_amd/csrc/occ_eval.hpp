@@ -153,6 +153,13 @@ struct RasterParams {
     const float* cam;
     int K;
     int ntx;  // tiles per image side
+    // Small launches (a single env, a handful of reset candidates): every 8x8 tile is handed out as 1 << split_log2
+    // work items of 8 >> split_log2 pixel rows each, so that one env's render is not bounded by the few waves its tiles
+    // would occupy (a tile that needs the exact top-K keeps one wave busy for up to a millisecond).  All sub-items
+    // stage the SAME faces in the SAME batches as the whole tile would - only the pairs of their own rows are
+    // evaluated - so every pixel sees the same candidates in the same order with the same accumulator copies:
+    // results do not depend on the split.
+    int split_log2;
 };
 
 // XCD-major order of the (env, object) pairs: env e belongs to XCD group e % 8; group g holds MQ = 3*ceil(N/8) slots.

@@ -225,16 +225,14 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
     if (hard && !out->obs) return OCC_ERR_ARG;
     if (soft && (faces_per_pixel <= 0 || faces_per_pixel > OCC_MAX_K)) return OCC_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(ws->queue, 0, 8 * 16 * sizeof(uint32_t), st) != hipSuccess) return OCC_ERR_LAUNCH;
     const int N = scene->n_env;
     const OccWorkspace& wsv = *ws;
-    if (wsv.order && hipMemsetAsync(wsv.order, 0, kOrdBlk * sizeof(uint32_t), st) != hipSuccess) return OCC_ERR_LAUNCH;
-    if (ws->rec_off) {
-        if (ws->rec_total <= 0 || (ws->rec_total & 63)) return OCC_ERR_ARG;
-        hipLaunchKernelGGL(occ_recoff_kernel, dim3(1), dim3(1024), 0, st, *scene, (long long*)ws->rec_off,
-                           (long long)ws->rec_total, ws->status);
-        OCC_DBG_SYNC("recoff");
-    }
+    if (ws->rec_off && (ws->rec_total <= 0 || (ws->rec_total & 63))) return OCC_ERR_ARG;
+    static_assert(kOrdBlk <= 1024, "occ_recoff_kernel zeroes the order header with one block");
+    // prologue: zero the queue heads and the order header, lay out the variable record spans
+    hipLaunchKernelGGL(occ_recoff_kernel, dim3(1), dim3(1024), 0, st, *scene, (long long*)ws->rec_off, (long long)ws->rec_total,
+                       ws->status, ws->queue, wsv.order);
+    OCC_DBG_SYNC("recoff");
     if (grad)
         hipLaunchKernelGGL(occ_setup_kernel<true>, dim3(N * 3), dim3(256), 0, st, *scene, cam, wsv);
     else
@@ -255,6 +253,13 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
     P.cam = cam;
     P.K = faces_per_pixel;
     P.ntx = scene->img / OCC_TILE;
+    {   // small launches: split every tile into row groups until the expected work items fill about half the grid
+        // (an object's rect covers a few per cent of the image: 0.04 x tiles is the typical count at radius 4)
+        const double est = (double)N * 3.0 * P.ntx * P.ntx * 0.04;
+        int sl = 0;
+        while (sl < 3 && est * (double)(2 << sl) <= (double)ws->n_slots) ++sl;
+        P.split_log2 = sl;
+    }
     if (wsv.order) {
         hipLaunchKernelGGL(occ_order_kernel, dim3(N * 3), dim3(64), 0, st, ws->objrect, ws->nrec, wsv.order, N, scene->img);
         OCC_DBG_SYNC("order");

@@ -181,20 +181,22 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
     const int mq = xcd_slots(P.sc.n_env), MP = 8 * mq;
     const int my_xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;  // steers which queue is drained first only
     int qround = 0;
+    const int sl = P.split_log2;  // a tile = 1 << sl work items of 8 >> sl pixel rows (RasterParams)
     const int myslot = acc_slot(0, lane);  // accumulator slot (copy 0) of the pixel this lane owns
     OCC_T_DECL;
 
     for (;;) {
         OCC_T(9);  // previous item's result stores
-        int item = -1;
+        int item = -1, sub = 0;
         while (qround < 8) {
             const int qq = (my_xcc + qround) & 7;
-            const int qbeg = ord ? ord[qq] : offs[qq * mq], qend = ord ? ord[qq + 1] : offs[(qq + 1) * mq];
+            const int qbeg = (ord ? ord[qq] : offs[qq * mq]) << sl, qend = (ord ? ord[qq + 1] : offs[(qq + 1) * mq]) << sl;
             int t = qend;
             if (lane == 0 && qbeg < qend) t = qbeg + (int)atomicAdd(P.ws.queue + qq * 16, 1u);
             t = __builtin_amdgcn_readfirstlane(t);
             if (t < qend) {
-                item = t;
+                item = t >> sl;
+                sub = t & ((1 << sl) - 1);
                 break;
             }
             qround += 1;
@@ -226,6 +228,9 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
         const int x0t = (tx0 + local % tw) * kT2, y0t = (ty0 + local / tw) * kT2;
         if (!OCC_BOUND(!(x0t < 0 || y0t < 0 || x0t + kT2 > S || y0t + kT2 > S), 46, eo, local)) continue;  // never true for a sane rect
         const int xi = x0t + (lane & 7), yi = y0t + (lane >> 3);  // the pixel this lane OWNS (lane = pixel)
+        // pixel rows of the tile that THIS item evaluates and writes (all eight unless the launch splits its tiles)
+        const int row_lo = sub << (3 - sl), row_hi = row_lo + (8 >> sl) - 1;
+        const bool my_rows = (lane >> 3) >= row_lo && (lane >> 3) <= row_hi;
         const int n = as_const(P.ws.nrec + eo)[0];
         const RecSpan span = rec_span(P.ws, cap, eo);
         if (!OCC_BOUND(!(n < 0 || n > span.cap), 47, n, eo)) continue;
@@ -644,8 +649,8 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             if (lane < nst) {
                 const uint2 bb = s_box[boff + lane];
                 cx0 = max((int)(bb.x & 0xFFFFu), x0t);
-                cy0 = max((int)(bb.x >> 16), y0t);
-                const int cx1 = min((int)(bb.y & 0xFFFFu), x0t + kT2 - 1), cy1 = min((int)(bb.y >> 16), y0t + kT2 - 1);
+                cy0 = max((int)(bb.x >> 16), y0t + row_lo);
+                const int cx1 = min((int)(bb.y & 0xFFFFu), x0t + kT2 - 1), cy1 = min((int)(bb.y >> 16), y0t + row_hi);
                 cw = cx1 - cx0 + 1;
                 c = max(cw, 0) * max(cy1 - cy0 + 1, 0);
                 cw = max(cw, 1);
@@ -659,19 +664,23 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 ptot += __popcll(mb) << b;
             }
             // Pair p of the batch belongs to the face with the largest pre <= p.  Instead of writing one descriptor per
-            // pair, every face marks its FIRST pair in a byte map; a round ballots its 64 flags and a lane's face is
-            // the running face count plus the marks at or below it.  (pre, clip origin, width, 2^15 / width) of every
-            // face replace its bbox in s_box.
+            // pair, every face that HAS pairs marks its FIRST pair in a byte map; a round ballots its 64 flags and a
+            // lane's face is the running count of such faces plus the marks at or below it.  (pre, clip origin, width,
+            // staged slot, 2^15 / width) of the r-th face with pairs replace the bbox in s_box[r].  (A face always has a
+            // pixel in the tile; it can be without pairs only in a row group of a split tile, RasterParams.split_log2.)
             auto mark_pairs = [&]() __attribute__((always_inline)) {
                 const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
                 reinterpret_cast<uint4*>(s_flag)[lane] = z4;
                 reinterpret_cast<uint4*>(s_flag)[lane + 64] = z4;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
-                if (lane < nst) {
+                const bool has = lane < nst && c > 0;
+                const int r = lane_rank(__ballot(has));
+                if (has) {
                     const uint32_t inv15 = (32768u + (uint32_t)cw - 1u) / (uint32_t)cw;
-                    s_box[boff + lane] = make_uint2((uint32_t)pre, (uint32_t)(cx0 - x0t) | ((uint32_t)(cy0 - y0t) << 3) | ((uint32_t)(cw - 1) << 6) | (inv15 << 16));
-                    if (lane > 0) s_flag[pre] = 1;
+                    s_box[boff + r] = make_uint2((uint32_t)pre, (uint32_t)(cx0 - x0t) | ((uint32_t)(cy0 - y0t) << 3) | ((uint32_t)(cw - 1) << 6) |
+                                                                    ((uint32_t)lane << 9) | (inv15 << 16));
+                    if (r > 0) s_flag[pre] = 1;
                 }
             };
             OCC_STAT(1, 1);      // staged batches
@@ -729,9 +738,10 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     const bool live = lane < nlive;
                     const bool mark = live && s_flag[p0 + lane] != 0;
                     const unsigned long long mk = __ballot(mark);
-                    const int f = live ? fbase + lane_rank(mk) + (mark ? 1 : 0) : 0;
+                    const int fr = live ? fbase + lane_rank(mk) + (mark ? 1 : 0) : 0;  // rank among the faces with pairs
                     fbase += __popcll(mk);
-                    const uint2 fg = s_box[boff + f];
+                    const uint2 fg = s_box[boff + fr];
+                    const int f = live ? (int)((fg.y >> 9) & 31u) : 0;  // its staged slot
                     const uint32_t jj = live ? (uint32_t)(p0 + lane) - fg.x : 0u;
                     // jj / width (exact for jj < 64, width <= 8); 24-bit multiplies: full rate (v_mul_lo_u32 is quarter rate)
                     const uint32_t wq = mul24(jj, fg.y >> 16) >> 15;
@@ -910,14 +920,16 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 sge = a.y;
                 sga = a.z;
             }
-            P.ws.obj_alpha[opix] = 1.0f - prod;
-            if (GRAD) {
-                // d alpha/d theta = -(A/sigma) * sum_k p_k d(d_k)/d theta   
-                const float coef = -prod * kInvSigma;
-                reinterpret_cast<float2*>(P.ws.obj_grad)[opix] = make_float2(coef * sge, coef * sga);
+            if (my_rows) {
+                P.ws.obj_alpha[opix] = 1.0f - prod;
+                if (GRAD) {
+                    // d alpha/d theta = -(A/sigma) * sum_k p_k d(d_k)/d theta   
+                    const float coef = -prod * kInvSigma;
+                    reinterpret_cast<float2*>(P.ws.obj_grad)[opix] = make_float2(coef * sge, coef * sga);
+                }
             }
         }
-        if (HARD) {
+        if (HARD && my_rows) {
             const unsigned long long h = s_hard[lane];
             const bool any = h != ~0ull;
             P.ws.obj_hz[opix] = any ? unzkey((uint32_t)(h >> 32)) : 3.0e38f;

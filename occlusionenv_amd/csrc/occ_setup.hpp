@@ -217,11 +217,17 @@ __device__ __forceinline__ RecSpan rec_span(const OccWorkspace& ws, int rec_cap,
 // Variable record layout: every (env, object) gets room for 2 x the faces of ITS mesh (a z-clipped face can split in
 // two), rounded up to 64; skipped scene rows get none.  One block: prefix sum over 3*n_env entries.
 // Objects that no longer fit into rec_total get an empty span and raise OCC_STATUS_REC_OVERFLOW.
+// The launch's prologue as well: the eight work-queue heads and the header of the work-item order are zeroed here
+// (two memset launches less in a sequence of ~25 dependent small launches at ~5 us each).
 __global__ __launch_bounds__(1024) void occ_recoff_kernel(OccScene sc, long long* __restrict__ rec_off, long long rec_total,
-                                                          int* __restrict__ status) {
+                                                          int* __restrict__ status, uint32_t* __restrict__ queue,
+                                                          uint32_t* __restrict__ order_hdr) {
     __shared__ long long s_part[16];
     __shared__ long long s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 8 * 16) queue[tid] = 0u;
+    if (order_hdr && tid < kOrdBlk) order_hdr[tid] = 0u;
+    if (!rec_off) return;  // fixed record layout: nothing to lay out
     const int M = 3 * sc.n_env;
     if (tid == 0) s_carry = 0;
     __syncthreads();

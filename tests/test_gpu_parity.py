@@ -286,3 +286,18 @@ def test_results_do_not_depend_on_the_work_item_order():
     for k in keys:
         assert torch.equal(runs[0][k], runs[1][k]), k
         assert torch.equal(runs[0][k], runs[2][k]), (k, "rect order")
+
+
+def test_small_launch_split_tiles_equal_the_big_launch_bitwise():
+    """A small launch (one env) hands every 8x8 tile out as eight row groups (RasterParams.split_log2 = 3, so that the
+    render is spread over the chip), a launch of 64 envs at 128x128 takes whole tiles: every output of env 0 must be
+    bit-identical between the two - the row groups stage the same faces in the same batches."""
+    from tests.parity_utils import make_case, run_engine
+
+    keys = ("obs0", "alphas0", "loss0", "obs", "alphas", "fs", "loss", "reward", "grad")
+    for mesh, seed in (("teapot", 77), ("mixed", 78)):
+        big = run_engine(make_case(64, seed, mesh, az_range=2.0), 128)
+        one = run_engine(make_case(64, seed, mesh, az_range=2.0), 128, n_env=1)
+        for k in keys:
+            assert torch.equal(big[k][:1], one[k]), (mesh, k)
+        assert torch.equal(big["obj_grad"][:1], one["obj_grad"]), mesh
