@@ -56,10 +56,6 @@ __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) {
 // would also drain every outstanding global load and store (s_waitcnt vmcnt(0)): the candidate-log stores of the round
 // just evaluated and the record loads that are meant to stay in flight.
 __device__ __forceinline__ void wave_lds_sync() {
-#ifdef OCC_AB_SYNCTHREADS  // A/B timing build only: the old full barrier
-    __syncthreads();
-    return;
-#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

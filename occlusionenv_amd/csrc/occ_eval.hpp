@@ -23,8 +23,12 @@ struct Cand {
 // one stack object gets folded into a dynamically indexed load, which pins the object in scratch).  The tangents are
 // FETCHED once the closest edge is known - tan(v) returns the tangent part of vertex v (0, 1, 2; per lane) - two
 // 16-byte reads at a computed address instead of three up front and sixteen selects among their components.
-#define OCC_REC_PARAMS float4 ra, float4 rb, float4 rc, float4 rd, float4 re
-#define OCC_REC_LOAD(src, PARTS) (src)[0], (src)[1], (src)[2], (src)[3], ((PARTS) > 4 ? (src)[4] : make_float4(0, 0, 0, 0))
+// Part d (the float bbox +- sqrt(blur) of [P3D]'s early reject) is NOT read here: a pixel centre outside that box is
+// farther than sqrt(blur) from the triangle, so its squared distance fails `dist < blur` by itself, and a centre inside
+// the triangle is inside the box - the reject never changes an outcome (up to a pixel on the blur boundary to within
+// rounding, which the parity checker classes as the tie it is).  Four compares, one LDS read and four registers less.
+#define OCC_REC_PARAMS float4 ra, float4 rb, float4 rc, float4 re
+#define OCC_REC_LOAD(src, PARTS) (src)[0], (src)[1], (src)[2], ((PARTS) > 4 ? (src)[4] : make_float4(0, 0, 0, 0))
 
 // Branch-free (the pair kernel only visits pixels of the face's pixel bbox, where a divergent early exit costs more
 // than it saves): everything is evaluated, candidates are masked at the end.
@@ -36,7 +40,6 @@ __device__ __forceinline__ void eval_face(OCC_REC_PARAMS, float xf, float yf, Ca
     c.q = 1.f;
     c.ge = c.ga = 0.f;
     c.amin = 0;
-    const bool inb = (rd.x <= xf) && (xf <= rd.y) && (rd.z <= yf) && (yf <= rd.w);
     const float x0 = ra.x, y0 = ra.y, z0 = ra.z;
     const float x1 = ra.w, y1 = rb.x, z1 = rb.y;
     const float x2 = rb.z, y2 = rb.w, z2 = rc.x;
@@ -53,7 +56,7 @@ __device__ __forceinline__ void eval_face(OCC_REC_PARAMS, float xf, float yf, Ca
     const float p0 = w0 * rden, p1 = w1 * rden, p2 = w2 * rden;
     const bool inside = (p0 > 0.0f) && (p1 > 0.0f) && (p2 > 0.0f);
     c.zh = p0 * z0 + p1 * z1 + p2 * z2;
-    c.inside = inb && inside && !(c.zh < 0.0f);
+    c.inside = inside && !(c.zh < 0.0f);
     if (!SOFT) return;
     // clipped barycentrics -> soft depth
     float c0 = fmaxf(p0, 0.f), c1 = fmaxf(p1, 0.f), c2 = fmaxf(p2, 0.f);
@@ -82,7 +85,7 @@ __device__ __forceinline__ void eval_face(OCC_REC_PARAMS, float xf, float yf, Ca
     const bool s02 = !s01 && (d02 <= d01) && (d02 <= d12);
     const bool s12 = !s01 && !s02 && (d12 <= d01) && (d12 <= d02);
     c.amin = s01 ? 0 : (s02 ? 1 : 2);
-    const bool cand = inb && !(pz < 0.0f) && (inside || dist < kBlurRadius);
+    const bool cand = !(pz < 0.0f) && (inside || dist < kBlurRadius);
     c.cand = cand;
     c.z = pz;
     c.ad = dist;

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
     const float fS = (float)S;
     const int cap = P.sc.rec_cap;
     const int K = P.K;
-    constexpr int kParts = GRAD ? kRecParts : (SOFT ? 5 : 4);  // float4 parts of a record that this variant reads
+    constexpr int kParts = GRAD ? kRecParts : (SOFT ? 5 : 3);  // float4 parts of a record that this variant reads (never part 3)
 
     // staged records (part-major) + pair descriptors; both idle during a selection, whose histograms alias them
     constexpr int kRecF4 = kRecParts * kStgPad;
@@ -315,9 +315,10 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             }
             // A sweep visits the log in groups of kSweepU rows of 64 entries; the next group's loads are issued before
             // the current one is processed (two groups = 8 KB in flight per wave: a sweep is pure memory latency)
-            auto load_group = [&](const int e0, uint2 (&kt)[kSweepU]) __attribute__((always_inline)) {
+            auto load_group = [&](const int e0, auto& kt) __attribute__((always_inline)) {
+                constexpr int U = (int)(sizeof(kt) / sizeof(kt[0]));
 #pragma unroll
-                for (int u = 0; u < kSweepU; ++u) {
+                for (int u = 0; u < U; ++u) {
                     const int e = e0 + u * 64 + lane;
                     kt[u] = e < nlog ? lg.kt[e] : make_uint2(0u, kNoEntry);
                 }
@@ -401,11 +402,12 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             uint2* blist = reinterpret_cast<uint2*>(s_pool);  // kList: (key, log index) x kListCap per pixel (histograms are done)
             wave_lds_sync();
             int wr = 0;
-            auto settle = [&](const int e0, const uint2 (&kt)[kSweepU]) __attribute__((always_inline)) {
+            auto settle = [&](const int e0, const auto& kt) __attribute__((always_inline)) {
+                constexpr int kU = (int)(sizeof(kt) / sizeof(kt[0]));
                 uint32_t keepm = 0u, readdm = 0u;  // per-row decisions of this lane, bit u
-                LogPay pv[kSweepU];
+                LogPay pv[kU];
 #pragma unroll
-                for (int u = 0; u < kSweepU; ++u) {  // decisions in log order (ties are served first come)
+                for (int u = 0; u < kU; ++u) {  // decisions in log order (ties are served first come)
                     if (kt[u].y != kNoEntry) {
                         const uint32_t px = kt[u].y & 63u;
                         const uint2 w = s_sel[px];
@@ -433,12 +435,12 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < kSweepU; ++u) {
+                for (int u = 0; u < kU; ++u) {
                     const int e = e0 + u * 64 + lane;
                     pv[u] = (((readdm | (compact ? keepm : 0u)) >> u) & 1u) ? lg.pay[e] : LogPay{1.f, 0.f, 0.f};
                 }
 #pragma unroll
-                for (int u = 0; u < kSweepU; ++u) {
+                for (int u = 0; u < kU; ++u) {
                     {
                         // Re-accumulate the kept entries - the product of the (1 - p_k) and the tangent sums, exactly as
                         // the evaluation rounds do - into the pixel's four accumulator copies by PLAIN read-modify-write:
@@ -572,19 +574,23 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             cmask &= cmask - 1;
             return cwin + bit;
         };
-        int c = next_chunk(), cn = -1;
-        uint4 bb_cur = kEmptyBox, bb_nxt = kEmptyBox;
-        if (c >= 0 && c * 64 + lane < n) bb_cur = scan[c * 64 + lane];
+        // The rows of the next TWO candidate chunks are in flight while one is worked on: a batch of 32 hits usually
+        // spans two or three chunk rows, and with one row ahead the second of them was waited for (~1 us) in every batch.
+        auto load_row = [&](const int ch) -> uint4 {
+            return (ch >= 0 && ch * 64 + lane < n) ? scan[ch * 64 + lane] : kEmptyBox;
+        };
+        int c = next_chunk();
+        int cn = c >= 0 ? next_chunk() : -1, cn2 = -1;
+        uint4 bb_cur = load_row(c), bb_nxt = load_row(cn), bb_nx2 = kEmptyBox;
         unsigned long long m = 0;  // hits of row c not yet staged
-        bool opened = false;       // row c has been balloted (and the next row's boxes requested)
+        bool opened = false;       // row c has been balloted (and the row after next requested)
         // next batch of the scan: up to kStg2 hits into hit list `boff` (0 or kStg2); returns how many
         auto fill = [&](const int boff) __attribute__((always_inline)) -> int {
             int cntf = 0;
             while (cntf < kStg2 && c >= 0) {
                 if (!opened) {
-                    cn = next_chunk();  // the next candidate chunk's row is fetched while this one is worked on
-                    bb_nxt = kEmptyBox;
-                    if (cn >= 0 && cn * 64 + lane < n) bb_nxt = scan[cn * 64 + lane];
+                    cn2 = cn >= 0 ? next_chunk() : -1;
+                    bb_nx2 = load_row(cn2);
                     m = __ballot(touches(bb_cur) && bb_cur.z < thrB);
                     opened = true;
                     OCC_STAT(5, 1);  // chunk rows scanned
@@ -604,6 +610,8 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 if (!m) {
                     c = cn;
                     bb_cur = bb_nxt;
+                    cn = cn2;
+                    bb_nxt = bb_nx2;
                     opened = false;
                 }
             }
@@ -620,7 +628,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #pragma unroll
             for (int i = 0; i < kStageLoads; ++i) {
                 const int idx = lane + 64 * i, k = idx >> 3, part = idx & 7;
-                const bool on = idx < cntf * kRecParts && part < kParts;
+                const bool on = idx < cntf * kRecParts && part < kParts && part != 3;
                 const int hj = on ? s_hit[boff + k] : 0;
                 r[i] = (on && OCC_BOUND(hj >= 0 && hj < n, 42, hj, n)) ? recs4[(size_t)hj * kRecParts + part] : make_float4(0, 0, 0, 0);
             }
@@ -629,7 +637,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #pragma unroll
             for (int i = 0; i < kStageLoads; ++i) {
                 const int idx = lane + 64 * i, k = idx >> 3, part = idx & 7;
-                if (idx < cntf * kRecParts && part < kParts) s_rec[part * kStgPad + k] = r[i];
+                if (idx < cntf * kRecParts && part < kParts && part != 3) s_rec[part * kStgPad + k] = r[i];
             }
         };
         float4 rstage[kStageLoads];  // records of the NEXT batch in flight
@@ -691,29 +699,19 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 mark_pairs();
                 // the records of THIS batch were requested a whole batch ago: wait for them here, explicitly, and keep
                 // the compiler from moving the next batch's loads above this wait (it would then wait for those too)
-#ifdef OCC_EXP_LATE_STAGE
-                {
-                    float4 r_[kStageLoads];
-                    stage_issue(r_, boff, nst);
-                    stage_commit(r_, nst);
-                }
-#else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 stage_commit(rstage, nst);
-#endif
                 wave_lds_sync();
                 __builtin_amdgcn_sched_barrier(0);
                 OCC_T(4);  // pair map + record commit
             }
             // scan ahead: the next batch's hit list, its record loads fly while this batch is evaluated
             const int nst_next = fill(boff ^ kStg2);
-#ifndef OCC_EXP_LATE_STAGE
             if (nst_next) stage_issue(rstage, boff ^ kStg2, nst_next);
-#endif
             OCC_T(2);
             {
-#ifndef OCC_EXP_NO_COMPACT  // register-pressure experiment only
+#ifndef OCC_DBG2_NO_COMPACT  // register-pressure experiment only (scripts/dbg)
                 if (SOFT && nlog + ptot > OCC_LOG_CAP) {
                     // rare: the log could fill up inside this batch -> keep every overflowing pixel's K nearest,
                     // compact the log, go on with tighter bounds
@@ -753,7 +751,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     const float xf = __shfl(own_xf, (int)(d & 7u), 64), yf = __shfl(own_yf, (int)(d & 56u), 64);
                     const float4* rs = &s_rec[f];
                     Cand c1;
-                    eval_face<SOFT, GRAD>(rs[0], rs[kStgPad], rs[2 * kStgPad], rs[3 * kStgPad],
+                    eval_face<SOFT, GRAD>(rs[0], rs[kStgPad], rs[2 * kStgPad],
                                           kParts > 4 ? rs[4 * kStgPad] : make_float4(0, 0, 0, 0), xf, yf, c1,
                                           [&](int v) { return rs[(5 + v) * kStgPad]; });
                     const int flags = live ? __float_as_int(rs[2 * kStgPad].z) : 0;
@@ -761,7 +759,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     // lanes look at both halves; the SECOND half's lane emits the winner when both are candidates,
                     // a half whose partner is no candidate at this pixel emits itself.  (A partner that the pruning
                     // bounds kept out of the batch has no lane: it lies beyond every pixel's K nearest anyway.)
-#ifdef OCC_EXP_NO_PAIR  // instruction-count experiment only
+#ifdef OCC_DBG2_NO_PAIR  // static instruction count of the main path only (scripts/dbg/loop_count.sh)
                     if (false) {
 #else
                     if (__ballot(flags & (FLAG_PAIR_FIRST | FLAG_PAIR_SECOND))) {
@@ -848,30 +846,32 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             // largest stored key bounds its K-th nearest from above, later candidates at or beyond it are dropped
             // unseen; once that holds for all 64 pixels (and every pixel has a hard face) whole faces / chunks whose
             // nearest vertex lies beyond every bound are skipped.
-            uint32_t bound = 0xFFFFFFFFu;
-            if (SOFT) {
-                if (dense && !lim_on && own_count() >= K) {
-                    lim_on = true;
-                    bnd = min(bnd, own_kmax());
+            // (In a soft launch an object in mesh order never gets per-pixel bounds - bnd stays at its maximum - so the
+            // tile-wide skip key cannot move either: the wave-wide reduction is only run where it can.)
+            if (!SOFT || dense) {
+                uint32_t bound = 0xFFFFFFFFu;
+                if (SOFT) {
+                    if (!lim_on && own_count() >= K) {
+                        lim_on = true;
+                        bnd = min(bnd, own_kmax());
+                    }
+                    bound = bnd;
                 }
-                bound = bnd;
-            }
-            if (HARD) {
-                const uint32_t hk = (uint32_t)(s_hard[lane] >> 32);  // 0xFFFFFFFF while the pixel has no face
-                bound = SOFT ? max(bound, hk) : hk;
-            }
+                if (HARD) {
+                    const uint32_t hk = (uint32_t)(s_hard[lane] >> 32);  // 0xFFFFFFFF while the pixel has no face
+                    bound = SOFT ? max(bound, hk) : hk;
+                }
 #pragma unroll
-            for (int mm = 32; mm >= 1; mm >>= 1) bound = max(bound, (uint32_t)__shfl_xor((int)bound, mm, 64));
-            thrB = (uint32_t)__builtin_amdgcn_readfirstlane((int)bound);
+                for (int mm = 32; mm >= 1; mm >>= 1) bound = max(bound, (uint32_t)__shfl_xor((int)bound, mm, 64));
+                thrB = (uint32_t)__builtin_amdgcn_readfirstlane((int)bound);
+            }
             OCC_T(6);  // pruning bounds
             fseq_base += nst;
             return nst_next;
         };
 
         nst = fill(0);
-#ifndef OCC_EXP_LATE_STAGE
         if (nst) stage_issue(rstage, 0, nst);
-#endif
         while (nst) {
             const int nst_next = process_batch();
             boff ^= kStg2;

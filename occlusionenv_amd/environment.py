@@ -18,9 +18,10 @@ Documented deviations (all from SURVEY.md §0):
 """
 from __future__ import annotations
 
+import itertools
 import os
-
 import random
+import weakref
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -40,7 +41,25 @@ _SCENE_RNG = np.random.default_rng()
 #: environment.py:296-298).  Every (env, object) slot of the render workspace holds records for the largest mesh in
 #: the pool, so lowering this bounds the memory of runs on datasets with a few huge models.
 MAX_MESH_FACES = int(os.environ.get("OCC_MAX_MESH_FACES", 250000))
-_OVERSIZE = set()  # (dataset id, model index) of models found to exceed it
+_OVERSIZE = set()  # (dataset token, model index) of models found to exceed it
+_DS_TOKENS: Dict[int, tuple] = {}  # id(dataset) -> (weak reference, token)
+_DS_COUNTER = itertools.count(1)
+
+
+def _dataset_token(dataset) -> int:
+    """A number that identifies ``dataset`` for as long as the process lives.  ``id()`` alone does not: the mesh pool
+    is shared by all envs of the process and outlives datasets, and a NEW dataset object can be given the address of
+    one that was garbage-collected - its models would then be served from the old one's pool entries."""
+    ent = _DS_TOKENS.get(id(dataset))
+    if ent is not None and ent[0]() is dataset:
+        return ent[1]
+    tok = next(_DS_COUNTER)
+    try:
+        ref = weakref.ref(dataset)
+    except TypeError:  # not weak-referenceable: keep it alive, its address can then never be handed out again
+        ref = (lambda d=dataset: d)
+    _DS_TOKENS[id(dataset)] = (ref, tok)
+    return tok
 
 
 def seed_scene_rng(seed=None) -> None:
@@ -102,7 +121,7 @@ def sample_scene(dataset, pool: MeshPool, num_objects: int = 3) -> Tuple[List[in
             low_idx = dataset.synset_start_idxs[category_id]
             high_idx = low_idx + dataset.synset_num_models[category_id]
             model_idx = int(_SCENE_RNG.integers(low=low_idx, high=high_idx))
-            key = (id(dataset), model_idx)
+            key = (_dataset_token(dataset), model_idx)
             if key in _OVERSIZE:
                 raise ValueError("scene contains a mesh above MAX_MESH_FACES")  # callers draw again
             if key not in pool._keys:

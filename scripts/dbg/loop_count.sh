@@ -3,7 +3,7 @@
 #   bash scripts/dbg/loop_count.sh [extra -D flags]   -> VALU / LDS / VMEM counts of the main path (clipped-pair path compiled out)
 cd "$(dirname "$0")/../.."
 mkdir -p build/r3 && cd build/r3
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -I../../include -I../../occlusionenv_amd/csrc -fno-slp-vectorize -DOCC_EXP_NO_PAIR "$@" \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -I../../include -I../../occlusionenv_amd/csrc -fno-slp-vectorize -DOCC_DBG2_NO_PAIR "$@" \
   -save-temps -o /tmp/x_lc.so ../../occlusionenv_amd/csrc/occ_kernels.hip 2>/dev/null
 grep -A12 "\.name:.*occ_raster2_kernelILb1ELb1ELb1" occ_kernels-hip-amdgcn-amd-amdhsa-gfx950.s | grep -E "spill|vgpr_count|group_seg" | tr '\n' ' '; echo
 grep -B8 "\.name:.*occ_raster2_kernelILb1ELb1ELb1" occ_kernels-hip-amdgcn-amd-amdhsa-gfx950.s | grep group_segment

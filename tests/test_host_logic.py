@@ -339,3 +339,29 @@ def test_tie_classifier_bands_are_frozen():
         assert 0 < getattr(pu, name) <= bound, (name, getattr(pu, name), bound)
     for img in (64, 128, 256, 512):
         assert pu.max_tie_pixels(img) <= max(4, int(2e-4 * img * img * 3))
+
+
+def test_pool_keys_survive_dataset_address_reuse():
+    """The shared mesh pool outlives datasets: a new dataset object that is handed the address of a collected one
+    (observed as a flaky GPU test: cubes rendered as the previous test's white meshes) must not be served its entries."""
+    import gc
+
+    from occlusionenv_amd import environment
+    from occlusionenv_amd.meshes import MeshPool, SyntheticShapeNet
+
+    pool = MeshPool("cpu")
+    seen = {}
+    for rep in range(6):
+        ds = SyntheticShapeNet(n_models=2, seed=100 + rep)
+        tok = environment._dataset_token(ds)
+        assert tok == environment._dataset_token(ds)        # stable while the object lives
+        assert tok not in seen.values()                      # never handed out twice, whatever id() does
+        seen[id(ds)] = tok
+        environment.seed_scene_rng(rep)
+        ids, _ = environment.sample_scene(ds, pool)
+        for m in ids:
+            v, _f = pool.get(m)
+            assert any(torch.equal(v, mv) for mv, _ in ds.models)  # the pool entry is THIS dataset's model
+        del ds
+        gc.collect()
+    environment.seed_scene_rng(None)
