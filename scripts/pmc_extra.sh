@@ -2,7 +2,7 @@
 # Extra PMC passes for the raster kernel (instruction mix, LDS, L2): writes profiles/<round>_pmc_extra.json.
 #   bash scripts/pmc_extra.sh r01        (on a 1-GPU MI355X box; counters in separate runs, kernel-trace only)
 set -u
-R=${1:-r01}
+R=${1:-r03}
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 OUT=gpurun_out/${R}_extra
 mkdir -p "$OUT"
@@ -16,7 +16,7 @@ done
 python - "$OUT" "$R" <<'PY'
 import collections, csv, glob, json, os, sys
 out, rnd = sys.argv[1], sys.argv[2]
-KEY = ("occ_raster_kernel" if os.environ.get("OCC_RASTER", "")[:1] == "1" else "occ_raster2_kernel") + "<true, true, true>"
+KEY = "occ_raster2_kernel<true, true, true>"
 vals = {}
 for f in glob.glob(os.path.join(out, "p*", "*", "*counter_collection.csv")):
     agg = collections.defaultdict(list)

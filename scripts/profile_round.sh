@@ -3,7 +3,7 @@
 #   bash scripts/profile_round.sh r02
 # kernel-trace/stats and each PMC counter are collected in SEPARATE runs (MI355X_MICROARCH.md, rocprofv3 PMC slots).
 set -u
-R=${1:-r02}
+R=${1:-r03}
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 ROOTD=$PWD
 OUT=$ROOTD/gpurun_out/$R

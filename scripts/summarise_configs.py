@@ -12,7 +12,7 @@ for logf in sorted(glob.glob(os.path.join(out, "*.log"))):
         continue
     bench = json.loads(lines[-1])
     if tag == "n2_gloo":
-        json.dump(bench, open(os.path.join(root, "profiles", f"{rnd}_n2_gloo_rehearsal.json"), "w"))
+        json.dump(bench, open(os.path.join(root, "profiles", f"{rnd}_n2_gloo_selflaunch.json"), "w"), indent=1)
         print(tag, "%.0f steps/s, %.2f ms/step" % (bench["value"], bench["ms_per_step"]))
         continue
     f = sorted(glob.glob(os.path.join(out, tag, "*", "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)  # newest run

@@ -30,7 +30,7 @@ def counters(sub):
     return agg
 
 
-SHORT = "occ_raster_kernel" if os.environ.get("OCC_RASTER", "")[:1] == "1" else "occ_raster2_kernel"
+SHORT = "occ_raster2_kernel"
 KEY = SHORT + "<true, true, true>"
 summary = {"kernel": KEY, "kernel_short": SHORT, "note": "per-launch means over the full-batch step launches; FETCH_SIZE/WRITE_SIZE in KiB as "
            "rocprofv3 reports them; hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 x2 read "
