@@ -345,8 +345,7 @@ def main(argv=None):
             action = action.detach().requires_grad_(True)
             obs, rewards, dones, _infos = venv.step(action)
             rewards.sum().backward()  # differentiable-reward backward to the action (train_predict.py:52)
-            rec = rollout.pack_records(obs, action, logprob, rewards, dones)
-            rec[:, :256] = feats  # the state that produced the action (PPO.py:158)
+            rec = rollout.pack_records(obs, action, logprob, rewards, dones, features=feats)  # PPO.py:158: the acting state's
             agent.store(rollout.all_gather_records(rec))
             ppo_state["obs"] = obs
             if len(agent.records) >= args.rollout_T:

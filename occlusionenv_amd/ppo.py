@@ -161,8 +161,7 @@ def train_rollouts(venv, agent: BatchedPPO, n_updates: int = 1, T: int = 50, wit
                 rewards.sum().backward()
             if on_step is not None:
                 on_step(action, rewards)
-            rec = rollout.pack_records(obs, action, logprob, rewards, dones)
-            rec[:, :256] = feats  # the state that produced the action (PPO.py:158), not the next one
+            rec = rollout.pack_records(obs, action, logprob, rewards, dones, features=feats)  # PPO.py:158: the acting state's
             agent.store(rollout.all_gather_records(rec))
             rew_sum = rew_sum + rewards.detach().mean()
         st = agent.update()

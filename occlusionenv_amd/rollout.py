@@ -31,11 +31,13 @@ def pooled_features(obs: torch.Tensor) -> torch.Tensor:
     return F.adaptive_avg_pool2d(obs, 8).reshape(obs.shape[0], 256)
 
 
-def pack_records(obs, actions, logprob, rewards, dones) -> torch.Tensor:
-    """(n,4,S,S), (n,2), (n,), (n,), (n,) -> (n, 261) f32."""
-    n = obs.shape[0]
-    rec = torch.empty(n, RECORD_FLOATS, dtype=torch.float32, device=obs.device)
-    rec[:, :256] = pooled_features(obs)
+def pack_records(obs, actions, logprob, rewards, dones, features=None) -> torch.Tensor:
+    """(n,4,S,S), (n,2), (n,), (n,), (n,) -> (n, 261) f32.  ``features`` (n,256): the features of the state that
+    PRODUCED the action, when the caller already has them (PPO.py:157-158 stores those; the pooling pass over the
+    observation - it reads every pixel - is then skipped)."""
+    n = actions.shape[0]
+    rec = torch.empty(n, RECORD_FLOATS, dtype=torch.float32, device=actions.device)
+    rec[:, :256] = pooled_features(obs) if features is None else features
     rec[:, 256:258] = actions.detach()
     rec[:, 258] = logprob.detach()
     rec[:, 259] = rewards.detach()
