@@ -59,6 +59,9 @@ constexpr int kStgPad = 33;    // LDS stride (float4) between the parts of the s
 constexpr int kPairCap = 2048; // pairs per batch at most (kStg2 faces x 64 pixels): one byte each in the pair map
 constexpr int kSelBits = 5;    // radix-select digit: 32 u16 buckets = 16 dwords per pixel (4 KB, aliasing records + descriptors)
 constexpr int kSelDw = (1 << kSelBits) / 2;
+constexpr int kSelStride = kSelDw + 1;  // dwords per pixel in LDS: odd, so that lanes bumping the SAME bucket of different
+                                        // pixels (a face's pixels lie at one depth) fall on different banks; with the
+                                        // stride of 16 they shared two banks (SQ_LDS_BANK_CONFLICT / ACTIVE_INST_LDS 0.6-0.7)
 #ifndef OCC_SWEEP_U
 #define OCC_SWEEP_U 4
 #endif
@@ -152,15 +155,14 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
     __shared__ float4 s_pool[kRecF4 + kPairCap / 16];
     float4* const s_rec = s_pool;
     uint8_t* const s_flag = reinterpret_cast<uint8_t*>(s_pool + kRecF4);  // pair map: 1 = first pair of a face
-    // selection scratch on top of the same pool: 64 x kSelDw histogram dwords, then seven 64-entry arrays
-    static_assert(sizeof(float4) * (kRecF4 + kPairCap / 16) >= 64 * kSelDw * 4 + 64 * 4 * 8, "selection scratch does not fit");
-    uint32_t* const s_selbase = reinterpret_cast<uint32_t*>(s_pool) + 64 * kSelDw;
+    // selection scratch on top of the same pool: 64 x kSelStride histogram dwords, then four 64-entry arrays
+    static_assert(sizeof(float4) * (kRecF4 + kPairCap / 16) >= 64 * kSelStride * 4 + 64 * 4 * 4, "selection scratch does not fit");
+    static_assert((64 * kSelStride) % 4 == 0 && 64 * kSelStride * 4 >= 64 * kListCap * 8, "alignment of the arrays behind the histograms / boundary lists on top of them");
+    uint32_t* const s_selbase = reinterpret_cast<uint32_t*>(s_pool) + 64 * kSelStride;
     uint2* const s_sel = reinterpret_cast<uint2*>(s_selbase);            // selection window (low key, shift | 255 = idle)
     uint32_t* const s_take = s_selbase + 128;
     uint32_t* const s_lcnt = s_selbase + 192;   // boundary-list fill counts (final selection) ...
     uint32_t* const s_kmax2 = s_selbase + 192;  // ... or the kept entries' largest key (in-loop compaction): never both
-    // re-accumulated (prod (1 - p), sum g_el, sum g_az, count) of the pixels that went through selection
-    float4* const s_acc2 = reinterpret_cast<float4*>(s_selbase + 256);
     // two hit lists: while one batch is evaluated the next one is already scanned and its records are in flight
     __shared__ int s_hit[2 * kStg2];               // record index of every staged face
     __shared__ uint2 s_box[2 * kStg2];             // its pixel bbox (xl | yl << 16, xh | yh << 16), then (pre, geometry)
@@ -291,15 +293,17 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             return a[0];
         };
 
+        // re-accumulated (prod (1 - p), sum g_el, sum g_az, count) of THIS lane's pixel when it went through selection
+        float4 acc2 = make_float4(1.f, 0.f, 0.f, 0.f);
         // ---- exact top-K over the log for every pixel holding more than K entries ---------------------------
-        // Leaves the sums of those pixels' K nearest in s_acc2 (and s_kmax2 when compacting) and returns whether
+        // Leaves the sums of the lane's own pixel's K nearest in acc2 (and the largest kept key in s_kmax2 when compacting) and returns whether
         // this lane's pixel was one of them.  COMPACT also rewrites the log so that it holds exactly the entries still
         // accounted for, and folds the selected sums back into the accumulator copies.
         auto select_topk = [&](const bool compact) __attribute__((always_inline)) -> bool {
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every log entry written so far is in memory before it is swept
             wave_lds_sync();
             (void)OCC_BOUND(nlog >= 0 && nlog <= OCC_LOG_CAP, 44, nlog, compact);
-            uint32_t* hist = reinterpret_cast<uint32_t*>(s_pool);  // 64 pixels x kSelDw dwords (u16 buckets)
+            uint32_t* hist = reinterpret_cast<uint32_t*>(s_pool);  // 64 pixels x kSelStride dwords (32 u16 buckets + 1 pad)
             const int cnt = own_count();
             const bool ovf = cnt > K;
             // window start: a candidate's depth is a convex combination of its face's vertex depths, so no key lies
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             OCC_T(10);  // selection: set-up
             while (__ballot(!done)) {
 #pragma unroll
-                for (int i = 0; i < kSelDw; i += 4) reinterpret_cast<uint4*>(hist + lane * kSelDw)[i >> 2] = make_uint4(0u, 0u, 0u, 0u);
+                for (int i = 0; i < kSelStride; ++i) hist[lane + 64 * i] = 0u;  // the whole array, lane-contiguous
                 wave_lds_sync();
                 auto bump = [&](const uint2 (&kt)[kSweepU]) __attribute__((always_inline)) {
 #pragma unroll
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                             const uint2 w = s_sel[px];
                             if (w.y < 32u) {
                                 const uint32_t d = (kt[u].x - w.x) >> w.y;
-                                if (kt[u].x >= w.x && d < (1u << kSelBits)) atomicAdd(&hist[px * kSelDw + (d >> 1)], 1u << (16 * (d & 1u)));
+                                if (kt[u].x >= w.x && d < (1u << kSelBits)) atomicAdd(&hist[px * kSelStride + (d >> 1)], 1u << (16 * (d & 1u)));
                             }
                         }
                     }
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     bool found = false;
 #pragma unroll
                     for (int i = 0; i < kSelDw; ++i) {
-                        const uint32_t w = hist[lane * kSelDw + i];
+                        const uint32_t w = hist[lane * kSelStride + i];
                         const int c0 = (int)(w & 0xFFFFu), c1 = (int)(w >> 16);
                         if (!found && cum + c0 >= need) { found = true; bstar = 2 * i; mstar = c0; cumb = cum; }
                         cum += c0;
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             s_sel[lane] = make_uint2(L, ovf ? (uint32_t)sh | ((uint32_t)mode << 8) : 255u);
             s_take[lane] = mode == kAll ? 0x7FFFFFFFu : (uint32_t)max(need, 0);
             s_lcnt[lane] = 0u;  // kList: entries collected so far / compaction: largest kept key
-            s_acc2[lane] = make_float4(1.f, 0.f, 0.f, 0.f);
+            acc2 = make_float4(1.f, 0.f, 0.f, 0.f);
             if (ovf) {  // its accumulated state is void: the copies now collect the kept entries (product, sums, count)
 #pragma unroll
                 for (int cpy = 0; cpy < kCopies; ++cpy) s_acc[cpy * kAccStride + myslot] = make_float4(1.f, 0.f, 0.f, 0.f);
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 }
             }
             wave_lds_sync();
-            if (ovf) s_acc2[lane] = own_fold();
+            if (ovf) acc2 = own_fold();
             OCC_T(13);  // selection: final sweep
             if (!compact && __ballot(mode == kList)) {
                 // the owner lane picks the `need` nearest of its <= kListCap boundary entries by (key, log index) and
@@ -520,8 +524,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 LogPay pv[kListCap];
 #pragma unroll
                 for (int i = 0; i < kListCap; ++i) pv[i] = ((takem >> i) & 1u) ? lg.pay[be[i].y] : LogPay{1.f, 0.f, 0.f};
-                float4 a2 = s_acc2[lane];
-                float sl = a2.x, se = a2.y, sa = a2.z;
+                float sl = acc2.x, se = acc2.y, sa = acc2.z;
 #pragma unroll
                 for (int i = 0; i < kListCap; ++i) {
                     if ((takem >> i) & 1u) {
@@ -530,14 +533,13 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                         sa += pv[i].ga;
                     }
                 }
-                s_acc2[lane] = make_float4(sl, se, sa, a2.w);
+                acc2 = make_float4(sl, se, sa, acc2.w);
             }
             OCC_T(14);  // selection: boundary lists
             if (compact) {
                 nlog = wr;
                 if (ovf) {  // the selected sums become the pixel's accumulated state (copy 0; the others empty)
-                    const float4 a2 = s_acc2[lane];
-                    s_acc[myslot] = a2;
+                    s_acc[myslot] = acc2;
                     s_akm[myslot] = akm_enc(s_kmax2[lane]);
 #pragma unroll
                     for (int cpy = 1; cpy < kCopies; ++cpy) {
@@ -910,10 +912,9 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             OCC_T_ITEM(__ballot(ovf) != 0ull);
             float prod, sge, sga;
             if (selected) {
-                const float4 a2 = s_acc2[lane];
-                prod = a2.x;
-                sge = a2.y;
-                sga = a2.z;
+                prod = acc2.x;
+                sge = acc2.y;
+                sga = acc2.z;
             } else {
                 const float4 a = own_fold();
                 prod = a.x;
