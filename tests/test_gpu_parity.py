@@ -121,6 +121,12 @@ def test_img_256():
     _check(run_parity_case(n_env=1, img=256, seed=8, mesh="teapot"))
 
 
+def test_img_72_one_env_odd_tile_table():
+    """One env at 72x72: 81 tiles per object, an ODD number of tile-table words - the 8-byte work items behind it start
+    on the pad word that keeps them aligned (occ_common.hpp: ord_items_word)."""
+    _check(run_parity_case(n_env=1, img=72, seed=9, mesh="teapot"))
+
+
 def test_small_log_build_forces_inloop_compaction():
     """Same sources built with the smallest legal candidate log (OCC_LOG_CAP = 10 368 entries): dense tiles go through
     the in-loop keep-the-K-nearest compaction.  Runs in a child process because the library is chosen at load time."""
