@@ -59,7 +59,9 @@ __device__ __forceinline__ void eval_face(OCC_REC_PARAMS, float xf, float yf, Ca
     c.inside = inside && !(c.zh < 0.0f);
     if (!SOFT) return;
     // clipped barycentrics -> soft depth
-    float c0 = fmaxf(p0, 0.f), c1 = fmaxf(p1, 0.f), c2 = fmaxf(p2, 0.f);
+    // max(x, 0) as med3(x, 0, +inf): one instruction (fmaxf canonicalises its operand first: a second v_max each)
+    float c0 = __builtin_amdgcn_fmed3f(p0, 0.f, __builtin_inff()), c1 = __builtin_amdgcn_fmed3f(p1, 0.f, __builtin_inff()),
+          c2 = __builtin_amdgcn_fmed3f(p2, 0.f, __builtin_inff());
     const float rs = frcp(fmaxf(c0 + c1 + c2, kBaryClipMin));
     c0 *= rs;
     c1 *= rs;
@@ -109,13 +111,14 @@ __device__ __forceinline__ void eval_face(OCC_REC_PARAMS, float xf, float yf, Ca
         const float4 ta = tan(s12 ? 1 : 0), tb4 = tan(s01 ? 1 : 2);
         const float mxe = ta.x + tb * (tb4.x - ta.x), mye = ta.y + tb * (tb4.y - ta.y);
         const float mxa = ta.z + tb * (tb4.z - ta.z), mya = ta.w + tb * (tb4.w - ta.w);
-        const float any = (s01 || s02 || s12) ? 1.0f : 0.0f;
-        const float sp = (inside ? -p : p) * any;
+        const float sp = inside ? -p : p;  // (exactly one of s01 / s02 / s12 holds for finite distances)
         c.ge = sp * (gx * mxe + gy * mye);
         c.ga = sp * (gx * mxa + gy * mya);
     }
 }
 
+// the same key for a depth known not to be negative (every candidate: pz < 0 is rejected): one instruction
+__device__ __forceinline__ uint32_t zkey_pos(float z) { return __float_as_uint(z) | 0x80000000u; }
 __device__ __forceinline__ uint32_t zkey(float z) {
     const uint32_t b = __float_as_uint(z);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);

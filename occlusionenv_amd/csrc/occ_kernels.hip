@@ -32,6 +32,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "occ_constants.h"
 #include "occlusionenv_amd.h"
 

@@ -688,7 +688,8 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 const int r = lane_rank(__ballot(has));
                 if (has) {
                     const uint32_t inv15 = (32768u + (uint32_t)cw - 1u) / (uint32_t)cw;
-                    s_box[boff + r] = make_uint2((uint32_t)pre, (uint32_t)(cx0 - x0t) | ((uint32_t)(cy0 - y0t) << 3) | ((uint32_t)(cw - 1) << 6) |
+                    // geometry word: pixel of the face's first pair (6 bits), 8 - width (3 bits, 0..7), staged slot, 2^15 / width
+                    s_box[boff + r] = make_uint2((uint32_t)pre, (uint32_t)(cx0 - x0t) | ((uint32_t)(cy0 - y0t) << 3) | ((uint32_t)(8 - cw) << 6) |
                                                                     ((uint32_t)lane << 9) | (inv15 << 16));
                     if (r > 0) s_flag[pre] = 1;
                 }
@@ -733,24 +734,45 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #ifdef OCC_DBG2_NO_EVAL  // timing experiment only
                 if (ptot > 0) fbase = -1;
 #endif
-                for (int p0 = 0; p0 < ptot && fbase >= 0; p0 += 64) {
-                    const int nlive = min(64, ptot - p0);
-                    const bool live = lane < nlive;
-                    const bool mark = live && s_flag[p0 + lane] != 0;
+                // pair -> (staged slot, pixel, pixel centre) of one round.  (Issuing the decode of round r + 1 at the top of
+                // round r, so that its three dependent LDS round trips overlap the arithmetic: +1.5 % - the loop is bound by
+                // its VALU instruction count, and carrying the decoded values costs five of them.)
+                struct Dec {
+                    bool live;
+                    int f, pix, nlive;
+                    float xf, yf;
+                };
+                auto decode = [&](const int p0) __attribute__((always_inline)) -> Dec {
+                    Dec dc;
+                    dc.nlive = min(64, ptot - p0);
+                    const bool live = lane < dc.nlive;
+                    // Lanes past the batch's last pair run along UNMASKED (no exec-mask branches around the LDS reads): the
+                    // pair map is zero behind the last pair, so they decode to the last face with a pair index beyond its
+                    // count - in-range LDS addresses, a meaningless pixel - and every side effect below is guarded by `live`.
+                    const bool mark = s_flag[min(p0 + lane, kPairCap - 1)] != 0;
                     const unsigned long long mk = __ballot(mark);
-                    const int fr = live ? fbase + lane_rank(mk) + (mark ? 1 : 0) : 0;  // rank among the faces with pairs
+                    const int fr = fbase + lane_rank(mk) + (mark ? 1 : 0);  // rank among the faces with pairs
                     fbase += __popcll(mk);
                     const uint2 fg = s_box[boff + fr];
-                    const int f = live ? (int)((fg.y >> 9) & 31u) : 0;  // its staged slot
-                    const uint32_t jj = live ? (uint32_t)(p0 + lane) - fg.x : 0u;
-                    // jj / width (exact for jj < 64, width <= 8); 24-bit multiplies: full rate (v_mul_lo_u32 is quarter rate)
+                    dc.f = (int)((fg.y >> 9) & 31u);  // its staged slot
+                    const uint32_t jj = (uint32_t)(p0 + lane) - fg.x;
+                    // row = jj / width, column = jj - row * width: pixel = first + 8 row + column = first + jj + row (8 - width)
+                    // (exact for jj < 64, width <= 8); 24-bit multiplies: full rate (v_mul_lo_u32 is quarter rate)
                     const uint32_t wq = mul24(jj, fg.y >> 16) >> 15;
-                    const uint32_t px_ = (fg.y & 7u) + (jj - mul24(wq, ((fg.y >> 6) & 7u) + 1u)), py_ = ((fg.y >> 3) & 7u) + wq;
-                    const uint32_t d = (py_ << 3) | px_;
-                    const int pix = (int)d;
-                    (void)OCC_BOUND(f >= 0 && f < kStg2 && d < 64u, 43, f, d);
+                    const uint32_t d = ((fg.y & 63u) + jj + mul24(wq, (fg.y >> 6) & 7u)) & 63u;
+                    dc.pix = (int)d;
+                    dc.live = live;
+                    dc.xf = __shfl(own_xf, (int)(d & 7u), 64);
+                    dc.yf = __shfl(own_yf, (int)(d & 56u), 64);
+                    return dc;
+                };
+                for (int p0 = 0; p0 < ptot && fbase >= 0; p0 += 64) {
+                    const Dec cur = decode(p0);
+                    const bool live = cur.live;
+                    const int f = cur.f, pix = cur.pix, nlive = cur.nlive;
+                    const float xf = cur.xf, yf = cur.yf;
+                    (void)OCC_BOUND(!live || (f >= 0 && f < nst && (unsigned)pix < 64u), 43, f, pix);
                     const int j = s_hit[boff + f];
-                    const float xf = __shfl(own_xf, (int)(d & 7u), 64), yf = __shfl(own_yf, (int)(d & 56u), 64);
                     const float4* rs = &s_rec[f];
                     Cand c1;
                     eval_face<SOFT, GRAD>(rs[0], rs[kStgPad], rs[2 * kStgPad],
@@ -792,10 +814,10 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     }
                     if (HARD) {
                         if (live && c1.inside)
-                            atomicMin(&s_hard[pix], ((unsigned long long)zkey(c1.zh) << 32) | (unsigned)j);
+                            atomicMin(&s_hard[pix], ((unsigned long long)zkey_pos(c1.zh) << 32) | (unsigned)j);
                     }
                     if (SOFT) {
-                        const uint32_t key = zkey(c1.z);
+                        const uint32_t key = zkey_pos(c1.z);  // only read for candidates (pz >= 0)
                         // dense objects: the pixel's bound sits in its owner lane (bnd; only changes between batches)
                         uint32_t pbnd = 0xFFFFFFFFu;
                         if (dense) pbnd = (uint32_t)__shfl((int)bnd, pix, 64);
@@ -818,22 +840,29 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                             // accumulate: plain read-modify-write in sub-passes of four consecutive staged faces
                             const int f_first = __builtin_amdgcn_readfirstlane(f);
                             const int f_last = __builtin_amdgcn_readlane(f, nlive - 1);
-                            const int slot = acc_slot(f & (kCopies - 1), pix);
+                            // slot of (copy f & 3, pixel): the pixel's copy-0 slot is what its owner lane holds in myslot
+                            // (one cross-lane read instead of redoing acc_slot's arithmetic), the copy adds a constant
+                            const int slot = __shfl(myslot, pix, 64) + (int)__umul24((uint32_t)(f & (kCopies - 1)), (uint32_t)kAccStride);
                             const int grp = (f - f_first) >> kCopyBits;
                             const int nsub = ((f_last - f_first) >> kCopyBits) + 1;
-                            for (int sp = 0; sp < nsub; ++sp) {
-                                if (acc && grp == sp) {
-                                    float4 a = s_acc[slot];
-                                    a.x *= c1.q;
-                                    if (GRAD) {
-                                        a.y += c1.ge;
-                                        a.z += c1.ga;
+                            auto subpasses = [&](auto with_bound) __attribute__((always_inline)) {
+                                for (int sp = 0; sp < nsub; ++sp) {
+                                    if (acc && grp == sp) {
+                                        float4 a = s_acc[slot];
+                                        a.x *= c1.q;
+                                        if (GRAD) {
+                                            a.y += c1.ge;
+                                            a.z += c1.ga;
+                                        }
+                                        a.w += 1.0f;
+                                        s_acc[slot] = a;
+                                        if (decltype(with_bound)::value) s_akm[slot] = max(s_akm[slot], akm_enc(key));
                                     }
-                                    a.w += 1.0f;
-                                    s_acc[slot] = a;
-                                    if (dense) s_akm[slot] = max(s_akm[slot], akm_enc(key));
                                 }
-                            }
+                            };
+                            // (two loops: with one, the bound's encoding and address are computed for every object)
+                            if (dense) subpasses(std::true_type{});
+                            else subpasses(std::false_type{});
                             if (acc) kmx_lane = max(kmx_lane, key);
 #else
                             asm volatile("" ::"v"(c1.q), "v"(c1.ge), "v"(c1.ga));
