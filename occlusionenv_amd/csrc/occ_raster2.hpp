@@ -736,7 +736,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #endif
                 // pair -> (staged slot, pixel, pixel centre) of one round.  (Issuing the decode of round r + 1 at the top of
                 // round r, so that its three dependent LDS round trips overlap the arithmetic: +1.5 % - the loop is bound by
-                // its VALU instruction count, and carrying the decoded values costs five of them.)
+                // its VALU work, and carrying the decoded values costs five instructions; reading only the next round's mark bytes ahead: no change.)
                 struct Dec {
                     bool live;
                     int f, pix, nlive;
