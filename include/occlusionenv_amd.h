@@ -218,6 +218,17 @@ int occ_rasterize_meshes_naive(const float* face_verts, const int64_t* mesh_to_f
                                int n_meshes, int H, int W, float blur_radius, int faces_per_pixel,
                                int perspective_correct, int clip_barycentric_coords, int cull_backfaces,
                                int64_t* pix_to_face, float* zbuf, float* bary, float* dists, void* stream);
+/*
+ * The same K-buffers, bit for bit, from a tiled kernel: one wave per (mesh, 8x8-pixel tile) looks only at the faces whose
+ * bbox +- sqrt(blur) can reach a pixel centre of the tile and keeps the (depth, face) lists in LDS (F / faces-per-tile
+ * times less evaluation work than the naive kernel; the producer callers of MeshRasterizer should use).  Same arguments;
+ * faces_per_pixel above 1024 (64 KiB of lists) is served by the naive kernel.
+ */
+int occ_rasterize_meshes_tiled(const float* face_verts, const int64_t* mesh_to_face_first_idx,
+                               const int64_t* num_faces_per_mesh, const int64_t* clipped_faces_neighbor_idx,
+                               int n_meshes, int H, int W, float blur_radius, int faces_per_pixel,
+                               int perspective_correct, int clip_barycentric_coords, int cull_backfaces,
+                               int64_t* pix_to_face, float* zbuf, float* bary, float* dists, void* stream);
 int occ_rasterize_meshes_backward_dists(const float* face_verts, const int64_t* pix_to_face, const float* grad_dists,
                                         int64_t n_faces, int n_meshes, int H, int W, int faces_per_pixel,
                                         int perspective_correct, int clip_barycentric_coords, float* grad_face_verts,

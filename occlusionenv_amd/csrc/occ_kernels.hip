@@ -323,6 +323,28 @@ extern "C" int occ_rasterize_meshes_naive(const float* face_verts, const int64_t
     return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
 }
 
+extern "C" int occ_rasterize_meshes_tiled(const float* face_verts, const int64_t* mesh_to_face_first_idx,
+                                          const int64_t* num_faces_per_mesh, const int64_t* clipped_faces_neighbor_idx,
+                                          int n_meshes, int H, int W, float blur_radius, int faces_per_pixel,
+                                          int perspective_correct, int clip_barycentric_coords, int cull_backfaces,
+                                          int64_t* pix_to_face, float* zbuf, float* bary, float* dists, void* stream) {
+    if (!face_verts || !mesh_to_face_first_idx || !num_faces_per_mesh || !pix_to_face || !zbuf || !bary || !dists ||
+        n_meshes <= 0 || H <= 0 || W <= 0 || faces_per_pixel <= 0 || blur_radius < 0.f)
+        return OCC_ERR_ARG;
+    const size_t lds = (size_t)64 * faces_per_pixel * 8;
+    if (lds > 64 * 1024)  // beyond the (depth, face) lists the kernel keeps in LDS: same results from the naive kernel
+        return occ_rasterize_meshes_naive(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx,
+                                          n_meshes, H, W, blur_radius, faces_per_pixel, perspective_correct,
+                                          clip_barycentric_coords, cull_backfaces, pix_to_face, zbuf, bary, dists, stream);
+    KbufArgs a{face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, n_meshes, H, W,
+               faces_per_pixel, blur_radius, perspective_correct, clip_barycentric_coords, cull_backfaces, pix_to_face,
+               zbuf, bary, dists};
+    const int tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
+    hipLaunchKernelGGL(occ_rast_tiled_fwd_kernel, dim3((unsigned)(n_meshes * tiles_x * tiles_y)), dim3(64), lds,
+                       (hipStream_t)stream, a, tiles_x, tiles_y);
+    return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
+}
+
 extern "C" int occ_rasterize_meshes_backward_dists(const float* face_verts, const int64_t* pix_to_face,
                                                    const float* grad_dists, int64_t n_faces, int n_meshes, int H, int W,
                                                    int faces_per_pixel, int perspective_correct,

@@ -134,6 +134,189 @@ __global__ __launch_bounds__(64) void occ_rast_naive_fwd_kernel(KbufArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Tiled producer of the same K-buffers (occ_rasterize_meshes_tiled): one wave per (mesh, 8x8-pixel tile), lane = pixel.
+// The per-(face, pixel) arithmetic and the list rules are those of occ_rast_naive_fwd_kernel, statement for statement
+// (kbuf_eval below is that kernel's loop body): what changes is WHICH faces a pixel looks at and WHERE its list lives.
+//   * Faces are taken 64 at a time, one per lane; a lane applies the per-face rejects (back face, degenerate, behind the
+//     camera) and asks whether the face's bbox +- sqrt(blur) can hold ANY pixel centre of the tile.  A face that fails
+//     fails the naive kernel's own bbox test at every pixel of the tile, so skipping it changes nothing; the survivors
+//     are then visited in ascending face order by all 64 pixels - the order the naive kernel sees them in.
+//   * A pixel's list keeps (depth, face) only, in LDS, entry i of pixel l at [i * 64 + l] (lane-contiguous: no bank
+//     conflicts); signed distance and barycentrics are NOT carried along but re-derived from the face at the end -
+//     the same expressions on the same inputs give the same bits.  The farthest entry is found by scanning the LDS list
+//     (the naive kernel scans its list in the output arrays: two dependent global loads per entry and candidate).
+//   * At the end every lane sorts its <= K entries by (depth, face) in LDS and writes its K output slots once.
+// Bit-identical to the naive kernel on all four outputs (tests/test_gpu_rasterize_op.py), ~F / (faces per tile) times
+// less evaluation work.  Needs 64 * K * 8 bytes of LDS: K <= 1024 (the C entry point falls back to the naive kernel above that).
+// ------------------------------------------------------------------------------------------
+struct KbufFace {
+    float x0, y0, z0, x1, y1, z1, x2, y2, z2;
+};
+struct KbufHit {
+    bool ok;      // the face is a candidate at this pixel
+    bool inside;
+    float pz, dist, c0, c1, c2;
+    int amin;
+};
+// the naive kernel's per-(face, pixel) evaluation after the per-face rejects: bbox test ... blur test
+__device__ __forceinline__ KbufHit kbuf_eval(const KbufFace& v, float xf, float yf, float sqb, float blur, int persp, int clipb) {
+    KbufHit h;
+    h.ok = false;
+    h.inside = false;
+    h.pz = h.dist = h.c0 = h.c1 = h.c2 = 0.f;
+    h.amin = 0;
+    const float xmin = fminf(fminf(v.x0, v.x1), v.x2) - sqb, xmax = fmaxf(fmaxf(v.x0, v.x1), v.x2) + sqb;
+    const float ymin = fminf(fminf(v.y0, v.y1), v.y2) - sqb, ymax = fmaxf(fmaxf(v.y0, v.y1), v.y2) + sqb;
+    if (!((xmin <= xf && xf <= xmax) && (ymin <= yf && yf <= ymax))) return h;
+    const float ar = k_edge(v.x2, v.y2, v.x0, v.y0, v.x1, v.y1) + kEpsilon;
+    const float b0 = k_edge(xf, yf, v.x1, v.y1, v.x2, v.y2) / ar;
+    const float b1 = k_edge(xf, yf, v.x2, v.y2, v.x0, v.y0) / ar;
+    const float b2 = k_edge(xf, yf, v.x0, v.y0, v.x1, v.y1) / ar;
+    float p0 = b0, p1 = b1, p2 = b2;
+    if (persp) {
+        const float w0 = b0 * v.z1 * v.z2, w1 = v.z0 * b1 * v.z2, w2 = v.z0 * v.z1 * b2;
+        const float den = fmaxf(w0 + w1 + w2, kEpsilon);
+        p0 = w0 / den; p1 = w1 / den; p2 = w2 / den;
+    }
+    float c0 = p0, c1 = p1, c2 = p2;
+    if (clipb) {
+        c0 = fmaxf(p0, 0.0f); c1 = fmaxf(p1, 0.0f); c2 = fmaxf(p2, 0.0f);
+        const float sm = fmaxf(c0 + c1 + c2, kBaryClipMin);
+        c0 /= sm; c1 /= sm; c2 /= sm;
+    }
+    const float pz = c0 * v.z0 + c1 * v.z1 + c2 * v.z2;
+    if (pz < 0.0f) return h;
+    const float e01 = k_seg(xf, yf, v.x0, v.y0, v.x1, v.y1), e02 = k_seg(xf, yf, v.x0, v.y0, v.x2, v.y2),
+                e12 = k_seg(xf, yf, v.x1, v.y1, v.x2, v.y2);
+    const float dist = fminf(fminf(e01, e02), e12);
+    h.amin = (e01 <= e02 && e01 <= e12) ? 0 : ((e02 <= e01 && e02 <= e12) ? 1 : 2);
+    h.inside = p0 > 0.0f && p1 > 0.0f && p2 > 0.0f;
+    if (!h.inside && dist >= blur) return h;
+    h.ok = true;
+    h.pz = pz; h.dist = dist; h.c0 = c0; h.c1 = c1; h.c2 = c2;
+    return h;
+}
+__device__ __forceinline__ KbufFace kbuf_load(const float* __restrict__ face_verts, int64_t f) {
+    const float* v = face_verts + f * 9;
+    return KbufFace{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]};
+}
+
+__global__ __launch_bounds__(64) void occ_rast_tiled_fwd_kernel(KbufArgs a, int tiles_x, int tiles_y) {
+    extern __shared__ unsigned char kb_smem[];
+    const int K = a.K, lane = threadIdx.x;
+    float* sz = reinterpret_cast<float*>(kb_smem);            // [K][64] depths
+    int* sf = reinterpret_cast<int*>(kb_smem) + 64 * K;       // [K][64] packed face indices
+    const int tpm = tiles_x * tiles_y;
+    const int n = blockIdx.x / tpm, t = blockIdx.x - n * tpm;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int xi = tx * 8 + (lane & 7), yi = ty * 8 + (lane >> 3);
+    const bool valid = xi < a.W && yi < a.H;
+    const float yf = -1.0f + (2.0f * (float)(a.H - 1 - yi) + 1.0f) / (float)a.H;
+    const float xf = -1.0f + (2.0f * (float)(a.W - 1 - xi) + 1.0f) / (float)a.W;
+    // pixel centres of the tile: xf decreases with xi (NDC +X is left), yf with yi
+    const int xi1 = min(tx * 8 + 7, a.W - 1), yi1 = min(ty * 8 + 7, a.H - 1);
+    const float txmax = -1.0f + (2.0f * (float)(a.W - 1 - tx * 8) + 1.0f) / (float)a.W;
+    const float txmin = -1.0f + (2.0f * (float)(a.W - 1 - xi1) + 1.0f) / (float)a.W;
+    const float tymax = -1.0f + (2.0f * (float)(a.H - 1 - ty * 8) + 1.0f) / (float)a.H;
+    const float tymin = -1.0f + (2.0f * (float)(a.H - 1 - yi1) + 1.0f) / (float)a.H;
+    const float sqb = sqrtf(a.blur);
+    int qn = 0;
+    const int64_t f0 = a.first_idx[n], f1 = f0 + a.num_faces[n];
+    for (int64_t fc = f0; fc < f1; fc += 64) {
+        const int64_t fl = fc + lane;
+        bool hit = false;
+        if (fl < f1) {
+            const KbufFace v = kbuf_load(a.face_verts, fl);
+            const float area = k_edge(v.x0, v.y0, v.x1, v.y1, v.x2, v.y2);
+            hit = !(a.cull && area < 0.0f) && !(area <= kEpsilon && area >= -kEpsilon) && !(fmaxf(fmaxf(v.z0, v.z1), v.z2) < 0.0f);
+            const float xmin = fminf(fminf(v.x0, v.x1), v.x2) - sqb, xmax = fmaxf(fmaxf(v.x0, v.x1), v.x2) + sqb;
+            const float ymin = fminf(fminf(v.y0, v.y1), v.y2) - sqb, ymax = fmaxf(fmaxf(v.y0, v.y1), v.y2) + sqb;
+            // some centre of the tile inside [xmin, xmax] x [ymin, ymax]?  necessary: the ranges overlap
+            hit = hit && xmin <= txmax && txmin <= xmax && ymin <= tymax && tymin <= ymax;
+        }
+        unsigned long long m = __ballot(hit);
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            const int64_t f = fc + b;
+            const KbufFace v = kbuf_load(a.face_verts, f);  // wave-uniform address
+            const KbufHit h = kbuf_eval(v, xf, yf, sqb, a.blur, a.persp, a.clipb);
+            if (!(valid && h.ok)) continue;
+            // clipped-pair rule, incl. the shared-diagonal tie definition of DESIGN.md §2
+            int itop = -1;
+            const int64_t nb = a.neighbor ? a.neighbor[f] : -1;
+            if (nb != -1) {
+                for (int i = 0; i < qn; ++i)
+                    if ((int64_t)sf[i * 64 + lane] == nb) { itop = i; break; }
+            }
+            int slot = -1;
+            if (itop != -1) {
+                // closest edge and distance of the entry already in the list: recomputed from its face (what the naive
+                // kernel reads back from its dists slot is this very minimum)
+                const KbufFace u = kbuf_load(a.face_verts, nb);
+                const float g01 = k_seg(xf, yf, u.x0, u.y0, u.x1, u.y1), g02 = k_seg(xf, yf, u.x0, u.y0, u.x2, u.y2),
+                            g12 = k_seg(xf, yf, u.x1, u.y1, u.x2, u.y2);
+                const int amin_nb = (g01 <= g02 && g01 <= g12) ? 0 : ((g02 <= g01 && g02 <= g12) ? 1 : 2);
+                const float dist_nb = fminf(fminf(g01, g02), g12);
+                const bool shared_tie = (nb == f - 1 && amin_nb == 2 && h.amin == 0) || (nb == f + 1 && amin_nb == 0 && h.amin == 2);
+                if (!shared_tie && h.dist < dist_nb) slot = itop;
+            } else if (qn < K) {
+                slot = qn++;
+            } else {
+                // full: the candidate displaces the largest (z, f) entry if it is smaller
+                int im = 0;
+                float zm = sz[lane];
+                int fm = sf[lane];
+                for (int i = 1; i < K; ++i) {
+                    const float zi = sz[i * 64 + lane];
+                    const int fi = sf[i * 64 + lane];
+                    if (zi > zm || (zi == zm && fi > fm)) { im = i; zm = zi; fm = fi; }
+                }
+                if (h.pz < zm || (h.pz == zm && f < (int64_t)fm)) slot = im;
+            }
+            if (slot >= 0) {
+                sz[slot * 64 + lane] = h.pz;
+                sf[slot * 64 + lane] = (int)f;
+            }
+        }
+    }
+    if (!valid) return;
+    // ascending (z, f): insertion sort of this lane's column
+    for (int i = 1; i < qn; ++i) {
+        const float zi = sz[i * 64 + lane];
+        const int fi = sf[i * 64 + lane];
+        int j = i - 1;
+        while (j >= 0) {
+            const float zj = sz[j * 64 + lane];
+            const int fj = sf[j * 64 + lane];
+            if (!(zj > zi || (zj == zi && fj > fi))) break;
+            sz[(j + 1) * 64 + lane] = zj;
+            sf[(j + 1) * 64 + lane] = fj;
+            --j;
+        }
+        sz[(j + 1) * 64 + lane] = zi;
+        sf[(j + 1) * 64 + lane] = fi;
+    }
+    const long pix = ((long)n * a.H + yi) * a.W + xi;
+    int64_t* qf = a.p2f + pix * K;
+    float* qz = a.zbuf + pix * K;
+    float* qd = a.dists + pix * K;
+    float* qb = a.bary + pix * K * 3;
+    for (int i = 0; i < qn; ++i) {
+        const int f = sf[i * 64 + lane];
+        const KbufHit h = kbuf_eval(kbuf_load(a.face_verts, f), xf, yf, sqb, a.blur, a.persp, a.clipb);
+        qf[i] = f;
+        qz[i] = sz[i * 64 + lane];
+        qd[i] = h.inside ? -h.dist : h.dist;
+        qb[i * 3] = h.c0; qb[i * 3 + 1] = h.c1; qb[i * 3 + 2] = h.c2;
+    }
+    for (int i = qn; i < K; ++i) {
+        qf[i] = -1; qz[i] = -1.0f; qd[i] = -1.0f;
+        qb[i * 3] = qb[i * 3 + 1] = qb[i * 3 + 2] = -1.0f;
+    }
+}
+
 // dists part of RasterizeMeshesBackward: one thread per (pixel, k), atomicAdd into grad_face_verts
 __global__ __launch_bounds__(256) void occ_rast_naive_bwd_kernel(const float* __restrict__ face_verts,
                                                                  const int64_t* __restrict__ p2f,

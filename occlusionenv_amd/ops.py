@@ -20,7 +20,7 @@ def _p(t):
 
 class _RasterizeFaceVerts(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, face_verts, first_idx, num_faces, neighbor, H, W, blur_radius, K, persp, clipb, cull):
+    def forward(ctx, face_verts, first_idx, num_faces, neighbor, H, W, blur_radius, K, persp, clipb, cull, naive=False):
         lib = nat.load()
         if not face_verts.is_cuda:
             raise nat.NativeError("rasterize_meshes needs CUDA/ROCm tensors; there is no CPU fallback")
@@ -35,9 +35,9 @@ class _RasterizeFaceVerts(torch.autograd.Function):
         bary = torch.empty(N, H, W, K, 3, dtype=torch.float32, device=dev)
         dists = torch.empty(N, H, W, K, dtype=torch.float32, device=dev)
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        nat.check(lib.occ_rasterize_meshes_naive(_p(fv), _p(first_idx), _p(num_faces), _p(nb), N, H, W, float(blur_radius),
-                                                 K, int(persp), int(clipb), int(cull), _p(p2f), _p(zbuf), _p(bary),
-                                                 _p(dists), st), "occ_rasterize_meshes_naive")
+        fn = lib.occ_rasterize_meshes_naive if naive else lib.occ_rasterize_meshes_tiled
+        nat.check(fn(_p(fv), _p(first_idx), _p(num_faces), _p(nb), N, H, W, float(blur_radius), K, int(persp), int(clipb),
+                     int(cull), _p(p2f), _p(zbuf), _p(bary), _p(dists), st), "occ_rasterize_meshes")
         ctx.save_for_backward(fv, p2f)
         ctx.cfg = (N, H, W, K, int(persp), int(clipb))
         ctx.mark_non_differentiable(p2f, zbuf, bary)
@@ -49,28 +49,29 @@ class _RasterizeFaceVerts(torch.autograd.Function):
         fv, p2f = ctx.saved_tensors
         N, H, W, K, persp, clipb = ctx.cfg
         if g_dists is None:
-            return (torch.zeros_like(fv),) + (None,) * 10
+            return (torch.zeros_like(fv),) + (None,) * 11
         lib = nat.load()
         gfv = torch.empty_like(fv)
         st = C.c_void_p(torch.cuda.current_stream(fv.device).cuda_stream)
         nat.check(lib.occ_rasterize_meshes_backward_dists(_p(fv), _p(p2f), _p(g_dists.contiguous().float()), fv.shape[0], N, H,
                                                           W, K, persp, clipb, _p(gfv), st),
                   "occ_rasterize_meshes_backward_dists")
-        return (gfv,) + (None,) * 10
+        return (gfv,) + (None,) * 11
 
 
 def rasterize_meshes(face_verts: torch.Tensor, mesh_to_face_first_idx: torch.Tensor, num_faces_per_mesh: torch.Tensor,
                      image_size: int = 256, blur_radius: float = 0.0, faces_per_pixel: int = 8,
                      perspective_correct: bool = False, clip_barycentric_coords: bool = False,
-                     cull_backfaces: bool = False, clipped_faces_neighbor_idx: Optional[torch.Tensor] = None
-                     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+                     cull_backfaces: bool = False, clipped_faces_neighbor_idx: Optional[torch.Tensor] = None,
+                     naive: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """``(pix_to_face, zbuf, bary_coords, dists)`` like PyTorch3D's ``_C.rasterize_meshes`` with ``bin_size=0``.
     ``face_verts`` (F,3,3) packed (x_ndc, y_ndc, z_view) of all meshes (already z-clipped, see
-    ``clipped_faces_neighbor_idx``); ``image_size`` int or (H, W)."""
+    ``clipped_faces_neighbor_idx``); ``image_size`` int or (H, W).  ``naive=True`` runs the one-thread-per-pixel kernel
+    over all faces instead of the tiled one (``occ_rasterize_meshes_tiled``); the outputs are bit-identical."""
     H, W = (image_size, image_size) if isinstance(image_size, int) else image_size
     return _RasterizeFaceVerts.apply(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx,
                                      int(H), int(W), blur_radius, int(faces_per_pixel), perspective_correct,
-                                     clip_barycentric_coords, cull_backfaces)
+                                     clip_barycentric_coords, cull_backfaces, bool(naive))
 
 
 class _SigmoidAlphaBlend(torch.autograd.Function):
