@@ -263,7 +263,7 @@ def committed_profile(args, raster_short):
         try:
             pj = json.load(open(os.path.join(pdir, prof)))
             if pj.get("workload") == args.workload and pj.get("envs") == args.envs and pj.get("img") == args.img \
-                    and pj.get("pool_models", 64) == args.pool_models and pj.get("kernel_short", "occ_raster_kernel") == raster_short:
+                    and pj.get("pool_models", 64) == args.pool_models and pj.get("kernel_short") == raster_short:
                 return pj, prof
         except Exception:  # noqa: BLE001
             continue

@@ -117,12 +117,10 @@ __device__ __forceinline__ void eval_face(OCC_REC_PARAMS, float xf, float yf, Ca
     }
 }
 
-// the same key for a depth known not to be negative (every candidate: pz < 0 is rejected): one instruction
+// Order-preserving integer image of a depth that is known not to be negative (every candidate: pz < 0 is rejected): the
+// float's bits with the sign bit set (the general image, used by the setup kernel for vertex depths, complements
+// negative floats; the two agree on z >= 0).  unzkey() in occ_raster2.hpp inverts it.
 __device__ __forceinline__ uint32_t zkey_pos(float z) { return __float_as_uint(z) | 0x80000000u; }
-__device__ __forceinline__ uint32_t zkey(float z) {
-    const uint32_t b = __float_as_uint(z);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
 
 #ifdef OCC_DBG_BOUNDS  // diagnostic build only: index checks at every memory access of the raster kernel
 __device__ int g_dbg_fault[8];
@@ -133,16 +131,8 @@ __device__ int g_dbg_fault[8];
                        g_dbg_fault[4] = (int)(v1), 0)                          \
                     : 0),                                                      \
                false))
-#define OCC_WATCHDOG(code, v0, v1)                                              \
-    do {                                                                        \
-        if (++wd_iters > 4000000) {                                             \
-            (void)OCC_BOUND(false, (code), (v0), (v1));                         \
-            return;                                                             \
-        }                                                                       \
-    } while (0)
 #else
 #define OCC_BOUND(cond, code, v0, v1) true
-#define OCC_WATCHDOG(code, v0, v1) do { } while (0)
 #endif
 
 #ifdef OCC_DBG_STATS  // diagnostic build only: loop trip counts of the raster kernel
@@ -180,7 +170,7 @@ __device__ __forceinline__ int perm_to_eo(int p, int mq, int n_env) {
 
 // One block: exclusive prefix sum of the block counts of every (env, object) rect, in XCD-major order
 // -> work-item offsets (8*MQ + 1 entries).
-// shift = 0: work item = one OCC_BLOCK x OCC_BLOCK block of the rect (occ_raster_kernel); shift = 1: one 2 x 2 group of
+// shift = 0: work item = one OCC_BLOCK x OCC_BLOCK block of the rect; shift = 1 (what occ_render passes): one 2 x 2 group of
 // blocks = 8 x 8-pixel tile (occ_raster2_kernel).
 __global__ __launch_bounds__(1024) void occ_scan_kernel(const int* __restrict__ objrect, const int* __restrict__ nrec,
                                                         int* __restrict__ offsets, int n_env, int shift) {

@@ -1,17 +1,18 @@
-// occ_raster2.hpp -- pair-enumerating raster kernel (round 2): persistent wave64s, work item = (env, object, 8x8-pixel
-// tile), taken heaviest first from the XCD's queue (occ_order_kernel).
+// occ_raster2.hpp -- the raster kernel: persistent wave64s, work item = (env, object, 8x8-pixel tile) - or a group of its
+// pixel rows in a small launch - taken heaviest first from the XCD's queue (occ_order_kernel).
 // Part of the single translation unit occ_kernels.hip (included inside namespace occ; not a stand-alone header).
 //
-// What changed against occ_raster.hpp (4x4-pixel block x 4 face slots, every staged face evaluated at all 16 pixels,
-// one lane-strided 16-byte K-buffer store per candidate into per-lane lists):
+// How it works (round 2; the round-1 kernel - 4x4-pixel block x 4 face slots, every staged face evaluated at all 16
+// pixels, one lane-strided 16-byte K-buffer store per candidate into per-lane lists - was retired in round 3):
 //
 //   * LANE = (face, pixel) PAIR.  For every staged face the wave enumerates exactly the pixels of the face's pixel
-//     bbox (setup kernel, +-sqrt(blur)) that fall into the tile - about 20 per ShapeNet-size face, of which ~60 % turn
-//     out to be candidates (was: 64 lane-evaluations per (face, block), 26 % useful).  Pair descriptors
-//     (staged slot, pixel) are expanded into LDS from a wave prefix sum over the faces' pair counts; a round of the
-//     loop evaluates 64 consecutive pairs, each lane reading ITS face's record from an LDS image of the staged records
-//     (structure-of-parts, stride 65: conflict-free staging writes, near-broadcast reads - consecutive lanes
-//     share a face).
+//     bbox (setup kernel, +-sqrt(blur)) that fall into the tile - about 10 per ShapeNet-size face and tile, of which
+//     68 % turn out to be candidates (round 1: 64 lane-evaluations per (face, block), 26 % useful).  Every face marks
+//     its first pair in a byte map built from a wave prefix sum over the faces' pair counts; a round of the loop
+//     evaluates 64 consecutive pairs (face = running count + marks at or below the lane, pixel = first + jj +
+//     row (8 - width) from one multiply by 2^15 / width), each lane reading ITS face's record from an LDS image of the
+//     staged records (part-major, stride 33: conflict-free staging writes, near-broadcast reads - consecutive lanes
+//     share a face).  Lanes past the batch's last pair run along unmasked; every side effect is guarded.
 //   * PER-PIXEL STATE IN LDS, updated by whichever lane evaluated the candidate with PLAIN read-modify-write (LDS
 //     atomics retire about one lane per cycle on gfx950: five of them per candidate cost more than the evaluation,
 //     measured 2.1 of 4.9 ms): (product of (1 - p_k), tangent sums, count) as one float4 and the largest key, in FOUR
@@ -26,26 +27,30 @@
 //     read when some pixel of the tile collected more than K candidates, and not even written for a tile that at most
 //     K faces touch (its cost class, carried by the work item, says so).
 //   * BATCHES ARE PIPELINED.  While a batch of <= 32 faces is evaluated, the scan has already produced the next
-//     batch's hit list (second list in LDS) and its records are in flight into registers; they are committed to LDS
-//     when the next batch starts, behind an explicit s_waitcnt + sched_barrier (left to itself hipcc hoists the next
-//     loads above the wait for the current ones and then waits for both: measured, no gain).  A/B on one box:
-//     3.02 ms vs 3.23 ms without the pipelining, 3.72 ms for the round-1 kernel.
+//     batch's hit list (second list in LDS, two rows of the scan in flight) and its records are in flight into
+//     registers; they are committed to LDS when the next batch starts, behind an explicit s_waitcnt + sched_barrier
+//     (left to itself hipcc hoists the next loads above the wait for the current ones and then waits for both).
+//     Without the pipelining: +7 % (round 3: 2.45 vs 2.29 ms).
 //   * COOPERATIVE EXACT TOP-K.  Radix select (5 bits per level) over the log with all 64 lanes sweeping it
-//     contiguously; every entry bumps the LDS histogram of ITS pixel; the pixel's owner lane (lane = pixel) scans its
-//     32 buckets and narrows its window; sweeps keep two groups of four 512-byte loads in flight (a sweep with one
-//     dependent load per iteration is pure memory latency).  Afterwards one more sweep re-accumulates the kept entries
-//     of the overflowing pixels into the pixel's four accumulator copies by plain
-//     read-modify-write, one sub-pass per group of four faces (the tag's sequence number): three LDS float atomics per
-//     entry, colliding on the pixel, cost 0.28 of 2.39 ms; ranking the lanes of a row by pixel with six ballots was
-//     slower still.  When the log fills up (thousands of candidates per pixel: far cameras, dense meshes) the same
-//     machinery keeps each overflowing pixel's K nearest and compacts the log in place; pruning bounds as before.
-//   * TWELVE RESIDENT WAVES PER CU need <= 12.5 KB of LDS each (12 752 B still fits, 13 008 B does not; 12 240 B here;
-//     with 13 648 B one wave in twelve only started when another had finished): one accumulator slot per pixel with a rotated column, 16-bit key bounds,
-//     the per-pixel bound of dense objects read from its owner lane.  The kernel is latency-bound: 10 / 11 / 12 waves
-//     per CU = 2.66 / 2.52 / 2.42 ms.
+//     contiguously; every entry bumps the LDS histogram of ITS pixel (odd stride per pixel: a face's pixels bump the same
+//     bucket); the pixel's owner lane (lane = pixel) scans its 32 buckets and narrows its window; sweeps keep two groups
+//     of four 512-byte loads in flight (a sweep with one dependent load per iteration is pure memory latency).
+//     Afterwards one more sweep re-accumulates the kept entries of the overflowing pixels - products and sums exactly
+//     as the evaluation rounds form them - into the pixel's four accumulator copies by plain read-modify-write, one
+//     sub-pass per group of four faces (the tag's sequence number): three LDS float atomics per entry, colliding on the
+//     pixel, cost 0.28 of 2.39 ms; ranking the lanes of a row by pixel with six ballots was slower still.  When the log
+//     fills up (thousands of candidates per pixel: far cameras, dense meshes) the same machinery keeps each overflowing
+//     pixel's K nearest and compacts the log in place; pruning bounds for front-to-back-sorted (dense) objects.
+//   * TWELVE RESIDENT WAVES PER CU: three per SIMD is what <= 168 VGPRs allow (the evaluation alone holds 132-147, DESIGN
+//     section 5), and twelve need <= 12.5 KB of LDS each (12 752 B still fits, 13 008 B does not; 12 240 B here): one
+//     accumulator slot per pixel with a rotated column, 16-bit key bounds, the per-pixel bound of dense objects read from
+//     its owner lane.  10 / 11 / 12 waves per CU = 2.66 / 2.52 / 2.42 ms (round 2).
+//   * ONE WAVE PER WORKGROUP: cross-lane hand-over through LDS needs no __syncthreads() (occ_common.hpp: wave_lds_sync).
+//   * SMALL LAUNCHES SPLIT THEIR TILES into 1 << split_log2 row groups (RasterParams): same staging, same batches, same
+//     accumulator copies - bit-identical results - so that one env's render is not bounded by one wave per tile.
 //
-// Semantics are those of occ_raster.hpp: same eval_face, same candidate rule, same K-nearest-by-z
-// truncation, same clipped-pair rule, same hard nearest-face rule.
+// Semantics: eval_face of occ_eval.hpp, the candidate rule, the K-nearest-by-z truncation, the
+// clipped-pair rule and the hard nearest-face rule of [P3D].
 
 // OCC_LOG_CAP (include/occlusionenv_amd.h): log entries per wave; must hold a compacted log (64 * OCC_MAX_K) plus the
 // pairs of one batch
