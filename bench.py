@@ -361,6 +361,16 @@ def main(argv=None):
     for _ in range(args.warmup):
         one_step()
     if ppo_mode:
+        # warm-up of the learner too (untimed, on a throw-away agent fed random records): the first update of a process
+        # pays one-time costs - optimizer state, the GEMM library's kernel selection - that took 0.8 s against 72 ms for
+        # every later update
+        warm = ppo_mod.BatchedPPO(device=dev, seed=1, K_epochs=args.ppo_epochs)
+        for _ in range(args.rollout_T):
+            r = torch.randn(args.envs * world, rollout.RECORD_FLOATS, device=dev)
+            r[:, 260] = 0.0
+            warm.store(r)
+        warm.update()
+        del warm
         agent.records = []  # the timed region starts a fresh rollout
     nat.check(lib.occ_profile_enable(1), "occ_profile_enable")
     barrier()

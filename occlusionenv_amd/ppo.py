@@ -80,7 +80,8 @@ class BatchedPPO:
     """PPO (PPO.py:107-223) over batched rollouts.  Hyper-parameters default to trainRL.py:42-56."""
 
     def __init__(self, lr_actor: float = 3e-4, lr_critic: float = 1e-3, gamma: float = 0.99, K_epochs: int = 80,
-                 eps_clip: float = 0.2, action_std_init: float = 0.6, device=None, seed: Optional[int] = None):
+                 eps_clip: float = 0.2, action_std_init: float = 0.6, device=None, seed: Optional[int] = None,
+                 graph_epochs: bool = True):
         self.gamma, self.eps_clip, self.K_epochs = gamma, eps_clip, K_epochs
         self.action_std = action_std_init
         if seed is not None:
@@ -88,10 +89,16 @@ class BatchedPPO:
         self.policy = ActorCriticHeads(action_std_init=action_std_init).to(device)
         self.policy_old = ActorCriticHeads(action_std_init=action_std_init).to(device)
         self.policy_old.load_state_dict(self.policy.state_dict())
+        on_gpu = next(self.policy.parameters()).is_cuda
+        # capturable: the optimizer keeps its step count on the device, so that an epoch can be captured in a HIP graph
         self.optimizer = torch.optim.Adam([
             {"params": self.policy.action_head.parameters(), "lr": lr_actor},
             {"params": self.policy.value_head.parameters(), "lr": lr_critic},
-        ])
+        ], capturable=on_gpu)
+        # The K epochs of an update are one fixed launch sequence (~35 small kernels) over fixed-size tensors: on the GPU
+        # epochs 4..K are replays of ONE captured HIP graph (the first three run eagerly, as the capture's warm-up).
+        self.graph_epochs = bool(graph_epochs) and on_gpu
+        self._graph = None  # (key, graph, static inputs, static loss outputs)
         self.records = []  # list of (N_total, 261) tensors, one per step
 
     # ---- acting (PPO.py:152-164) ------------------------------------------------------------
@@ -113,6 +120,27 @@ class BatchedPPO:
         self.set_action_std(max(round(self.action_std - rate, 4), min_std))  # PPO.py:136-149
 
     # ---- learning (PPO.py:176-217) ----------------------------------------------------------
+    def _epoch_graph(self, epoch, feats, actions, old_lp, returns):
+        """The captured epoch for inputs of this shape: static copies of the four inputs, the graph, its two loss outputs.
+        Built after three eager epochs of the first update (optimizer state and library workspaces exist by then);
+        later updates of the same size copy their data into the static inputs and replay."""
+        key = (tuple(feats.shape), feats.device)
+        if self._graph is None or self._graph[0] != key:
+            static = [t.clone() for t in (feats, actions, old_lp, returns)]
+            side = torch.cuda.Stream(device=feats.device)
+            side.wait_stream(torch.cuda.current_stream(feats.device))
+            g = torch.cuda.CUDAGraph()
+            self.optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    out = epoch(*static)
+            torch.cuda.current_stream(feats.device).wait_stream(side)
+            self._graph = (key, g, static, out)
+        else:
+            for dst, src in zip(self._graph[2], (feats, actions, old_lp, returns)):
+                dst.copy_(src)
+        return self._graph
+
     def update(self) -> dict:
         rec = torch.stack(self.records)  # (T, N, 261)
         feats, actions = rec[..., :256], rec[..., 256:258]
@@ -122,7 +150,8 @@ class BatchedPPO:
         feats, actions = feats.reshape(-1, 256), actions.reshape(-1, 2)
         old_lp, returns = old_lp.reshape(-1), returns.reshape(-1)
         losses, vlosses = [], []
-        for _ in range(self.K_epochs):
+
+        def epoch(feats, actions, old_lp, returns):
             lp, value, ent = self.policy.evaluate(feats, actions)
             ratios = torch.exp(lp - old_lp)
             adv = returns - value.detach()
@@ -130,11 +159,34 @@ class BatchedPPO:
             surr2 = torch.clamp(ratios, 1 - self.eps_clip, 1 + self.eps_clip) * adv
             vloss = torch.mean((value - returns) ** 2)
             loss = (-torch.min(surr1, surr2) + 0.5 * vloss - 0.01 * ent).mean()
-            self.optimizer.zero_grad()
+            self.optimizer.zero_grad(set_to_none=True)
             loss.backward()
             self.optimizer.step()
-            losses.append(loss.detach())
-            vlosses.append(vloss.detach())
+            return loss.detach(), vloss.detach()
+
+        n_eager = self.K_epochs
+        if self.graph_epochs and self.K_epochs > 4:
+            n_eager = 3
+        for _ in range(n_eager):
+            l, v = epoch(feats, actions, old_lp, returns)
+            losses.append(l)
+            vlosses.append(v)
+        if n_eager < self.K_epochs:
+            try:
+                g = self._epoch_graph(epoch, feats, actions, old_lp, returns)
+                for _ in range(self.K_epochs - n_eager):
+                    g[1].replay()
+                    losses.append(g[3][0].clone())
+                    vlosses.append(g[3][1].clone())
+            except Exception as e:  # noqa: BLE001 - capture unsupported here: the same epochs, launched one by one
+                import warnings
+
+                warnings.warn(f"HIP-graph capture of the PPO epoch failed ({e!r}); running the epochs eagerly")
+                self.graph_epochs, self._graph = False, None
+                for _ in range(self.K_epochs - len(losses)):
+                    l, v = epoch(feats, actions, old_lp, returns)
+                    losses.append(l)
+                    vlosses.append(v)
         # one host sync for the whole update (the reference syncs nowhere inside its epoch loop either, PPO.py:196-217)
         losses, vlosses = torch.stack(losses).cpu(), torch.stack(vlosses).cpu()
         self.policy_old.load_state_dict(self.policy.state_dict())

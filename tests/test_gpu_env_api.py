@@ -640,3 +640,32 @@ def test_env_on_a_shapenetcore_directory(tmp_path):
     assert o.shape == (4, 1, 4, 64, 64)
     o2, r2, d2, _ = venv.step(torch.zeros(4, 2, device="cuda"))
     assert o2.shape == (4, 4, 64, 64) and torch.isfinite(r2).all()
+
+
+def test_graphed_ppo_epochs_equal_the_eager_ones():
+    """BatchedPPO.update on the GPU replays ONE captured HIP graph for epochs 4..K: the heads it leaves behind must be
+    those of the same epochs launched one by one, over two updates (the second reuses the graph with new data)."""
+    from occlusionenv_amd import ppo, rollout
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+    recs = []
+    for _u in range(2):
+        r = torch.randn(12, 96, rollout.RECORD_FLOATS, device="cuda", generator=g)
+        r[..., 258] = -2.0 + 0.1 * r[..., 258]          # old log-probabilities
+        r[..., 260] = (torch.rand(12, 96, device="cuda", generator=g) < 0.1).float()
+        recs.append(r)
+    heads = []
+    for graph in (True, False):
+        agent = ppo.BatchedPPO(device="cuda", seed=3, K_epochs=20, graph_epochs=graph)
+        stats = []
+        for r in recs:
+            for t in range(r.shape[0]):
+                agent.store(r[t])
+            stats.append(agent.update())
+        assert agent.graph_epochs == graph  # the capture did not fall back
+        heads.append(([p.detach().clone() for p in agent.policy.parameters()], stats))
+    for a, b in zip(heads[0][0], heads[1][0]):
+        assert torch.allclose(a, b, rtol=0, atol=1e-6), float((a - b).abs().max())
+    for sa, sb in zip(heads[0][1], heads[1][1]):
+        assert sa["samples"] == sb["samples"] == 12 * 96
+        assert abs(sa["loss_last"] - sb["loss_last"]) < 1e-5 and abs(sa["value_loss_last"] - sb["value_loss_last"]) < 1e-5
