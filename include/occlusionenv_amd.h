@@ -210,8 +210,8 @@ int occ_step_finish(const float* loss, const float* grad_elaz, const float* cam,
  * PyTorch3D's layout: pix_to_face (N,H,W,K) int64 (packed face index, -1 empty), zbuf, dists (N,H,W,K),
  * bary (N,H,W,K,3), slots ascending in (z, face).  Built for exactness (reference arithmetic order, no FMA
  * contraction), not speed: the fused occ_render never materialises these buffers.
- * grad_face_verts (F,3,3) is overwritten; only x,y receive gradient (zbuf / bary gradients are zero on the
- * OcclusionEnv path and are not computed).
+ * grad_face_verts (F,3,3) is overwritten; the dists entry point gives x,y their gradient (zbuf / bary gradients - zero on the
+ * OcclusionEnv path - come from occ_rasterize_meshes_backward below).
  */
 int occ_rasterize_meshes_naive(const float* face_verts, const int64_t* mesh_to_face_first_idx,
                                const int64_t* num_faces_per_mesh, const int64_t* clipped_faces_neighbor_idx,
@@ -233,6 +233,17 @@ int occ_rasterize_meshes_backward_dists(const float* face_verts, const int64_t* 
                                         int64_t n_faces, int n_meshes, int H, int W, int faces_per_pixel,
                                         int perspective_correct, int clip_barycentric_coords, float* grad_face_verts,
                                         void* stream);
+
+/*
+ * The whole of `_C.rasterize_meshes_backward`: grad_face_verts (F,3,3), overwritten, from any of grad_zbuf (N,H,W,K),
+ * grad_bary (N,H,W,K,3), grad_dists (N,H,W,K) - NULL = that output carries no gradient.  The dists part is
+ * occ_rasterize_meshes_backward_dists; zbuf / bary gradients (zero on the OcclusionEnv path) differentiate the
+ * area-normalised, perspective-corrected, clipped barycentrics and the depth they interpolate.
+ */
+int occ_rasterize_meshes_backward(const float* face_verts, const int64_t* pix_to_face, const float* grad_zbuf,
+                                  const float* grad_bary, const float* grad_dists, int64_t n_faces, int n_meshes, int H, int W,
+                                  int faces_per_pixel, int perspective_correct, int clip_barycentric_coords,
+                                  float* grad_face_verts, void* stream);
 
 /*
  * [P3D] sigmoid_alpha_blend (SoftSilhouetteShader, environment.py:263) on K-buffers in PyTorch3D layout:

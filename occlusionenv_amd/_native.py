@@ -136,6 +136,8 @@ SYMBOLS = {
                                              C.c_int, C.c_int] + [C.c_void_p] * 5),
     "occ_rasterize_meshes_backward_dists": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                                       C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "occ_rasterize_meshes_backward": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                C.c_int, C.c_void_p, C.c_void_p]),
     "occ_sigmoid_alpha_blend_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "occ_sigmoid_alpha_blend_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p,
                                               C.c_void_p]),

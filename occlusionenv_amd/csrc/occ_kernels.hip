@@ -361,6 +361,26 @@ extern "C" int occ_rasterize_meshes_backward_dists(const float* face_verts, cons
     return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
 }
 
+extern "C" int occ_rasterize_meshes_backward(const float* face_verts, const int64_t* pix_to_face, const float* grad_zbuf,
+                                             const float* grad_bary, const float* grad_dists, int64_t n_faces, int n_meshes,
+                                             int H, int W, int faces_per_pixel, int perspective_correct,
+                                             int clip_barycentric_coords, float* grad_face_verts, void* stream) {
+    if (!face_verts || !pix_to_face || !grad_face_verts || n_faces <= 0 || n_meshes <= 0 || H <= 0 || W <= 0 ||
+        faces_per_pixel <= 0)
+        return OCC_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(grad_face_verts, 0, (size_t)n_faces * 9 * sizeof(float), st) != hipSuccess) return OCC_ERR_LAUNCH;
+    const long tot = (long)n_meshes * H * W * faces_per_pixel;
+    const dim3 grid((unsigned)((tot + 255) / 256)), block(256);
+    if (grad_dists)
+        hipLaunchKernelGGL(occ_rast_naive_bwd_kernel, grid, block, 0, st, face_verts, pix_to_face, grad_dists, n_meshes, H, W,
+                           faces_per_pixel, perspective_correct, clip_barycentric_coords, grad_face_verts);
+    if (grad_zbuf || grad_bary)
+        hipLaunchKernelGGL(occ_rast_bwd_zbary_kernel, grid, block, 0, st, face_verts, pix_to_face, grad_zbuf, grad_bary,
+                           n_meshes, H, W, faces_per_pixel, perspective_correct, clip_barycentric_coords, grad_face_verts);
+    return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
+}
+
 extern "C" int occ_sigmoid_alpha_blend_fwd(const float* dists, const int64_t* pix_to_face, int64_t n_pix, int faces_per_pixel,
                                            float sigma, float* images, void* stream) {
     if (!dists || !pix_to_face || !images || n_pix <= 0 || faces_per_pixel <= 0 || !(sigma > 0.f)) return OCC_ERR_ARG;

@@ -362,4 +362,70 @@ __global__ __launch_bounds__(256) void occ_rast_naive_bwd_kernel(const float* __
     atomicAdd(gf + ib * 3, g * tt * 2.0f * dx);
     atomicAdd(gf + ib * 3 + 1, g * tt * 2.0f * dy);
 }
+
+// ------------------------------------------------------------------------------------------
+// zbuf / bary part of RasterizeMeshesBackward.  Zero on the OcclusionEnv path (the silhouette shader reads
+// dists only), built for callers of the rasteriser that shade with barycentrics or depth.  One thread per (pixel, k):
+// the forward formulas of A.4 - area-normalised edge functions, perspective correction, lower-bound clip with
+// renormalisation, depth - are re-evaluated in FORWARD mode, once per coordinate of the face (nine passes of a
+// value + one-derivative pair), and each pass's directional derivative of (bary, zbuf) is contracted with the
+// incoming gradients and added into grad_face_verts.  Kinks (max with a floor, clip at 0) take the derivative of the
+// active branch, 0 on the floor - the convention of [P3D]'s Barycentric*Backward.
+// ------------------------------------------------------------------------------------------
+struct D1 {
+    float v, d;
+};
+__device__ __forceinline__ D1 operator+(D1 a, D1 b) { return {a.v + b.v, a.d + b.d}; }
+__device__ __forceinline__ D1 operator-(D1 a, D1 b) { return {a.v - b.v, a.d - b.d}; }
+__device__ __forceinline__ D1 operator*(D1 a, D1 b) { return {a.v * b.v, a.d * b.v + a.v * b.d}; }
+__device__ __forceinline__ D1 operator/(D1 a, D1 b) { const float q = a.v / b.v; return {q, (a.d - q * b.d) / b.v}; }
+__device__ __forceinline__ D1 d1_const(float c) { return {c, 0.f}; }
+__device__ __forceinline__ D1 d1_max(D1 a, float floor_) { return a.v > floor_ ? a : D1{floor_, 0.f}; }
+__device__ __forceinline__ D1 d1_edge(D1 px, D1 py, D1 ax, D1 ay, D1 bx, D1 by) { return (px - ax) * (by - ay) - (py - ay) * (bx - ax); }
+
+__global__ __launch_bounds__(256) void occ_rast_bwd_zbary_kernel(const float* __restrict__ face_verts,
+                                                                 const int64_t* __restrict__ p2f,
+                                                                 const float* __restrict__ grad_zbuf,
+                                                                 const float* __restrict__ grad_bary, int N, int H, int W,
+                                                                 int K, int persp, int clipb,
+                                                                 float* __restrict__ grad_face_verts) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tot = (long)N * H * W * K;
+    if (t >= tot) return;
+    const int64_t f = p2f[t];
+    if (f < 0) return;
+    const float gz = grad_zbuf ? grad_zbuf[t] : 0.f;
+    const float g0 = grad_bary ? grad_bary[t * 3] : 0.f, g1 = grad_bary ? grad_bary[t * 3 + 1] : 0.f,
+                g2 = grad_bary ? grad_bary[t * 3 + 2] : 0.f;
+    if (gz == 0.f && g0 == 0.f && g1 == 0.f && g2 == 0.f) return;
+    const long pix = t / K;
+    const int rem = (int)(pix % ((long)H * W));
+    const int yi = rem / W, xi = rem - yi * W;
+    const float yf = -1.0f + (2.0f * (float)(H - 1 - yi) + 1.0f) / (float)H;
+    const float xf = -1.0f + (2.0f * (float)(W - 1 - xi) + 1.0f) / (float)W;
+    const float* v = face_verts + f * 9;
+    float* gf = grad_face_verts + f * 9;
+    const D1 px = d1_const(xf), py = d1_const(yf);
+    for (int j = 0; j < 9; ++j) {  // directional derivative along coordinate j of the face
+        D1 c[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) c[i] = D1{v[i], i == j ? 1.f : 0.f};
+        const D1 x0 = c[0], y0 = c[1], z0 = c[2], x1 = c[3], y1 = c[4], z1 = c[5], x2 = c[6], y2 = c[7], z2 = c[8];
+        const D1 ar = d1_edge(x2, y2, x0, y0, x1, y1) + d1_const(kEpsilon);
+        D1 p0 = d1_edge(px, py, x1, y1, x2, y2) / ar, p1 = d1_edge(px, py, x2, y2, x0, y0) / ar, p2 = d1_edge(px, py, x0, y0, x1, y1) / ar;
+        if (persp) {
+            const D1 w0 = p0 * z1 * z2, w1 = z0 * p1 * z2, w2 = z0 * z1 * p2;
+            const D1 den = d1_max(w0 + w1 + w2, kEpsilon);
+            p0 = w0 / den; p1 = w1 / den; p2 = w2 / den;
+        }
+        if (clipb) {
+            p0 = d1_max(p0, 0.0f); p1 = d1_max(p1, 0.0f); p2 = d1_max(p2, 0.0f);
+            const D1 sm = d1_max(p0 + p1 + p2, kBaryClipMin);
+            p0 = p0 / sm; p1 = p1 / sm; p2 = p2 / sm;
+        }
+        const D1 pz = p0 * z0 + p1 * z1 + p2 * z2;
+        const float g = g0 * p0.d + g1 * p1.d + g2 * p2.d + gz * pz.d;
+        if (g != 0.f) atomicAdd(gf + j, g);
+    }
+}
 #pragma clang fp contract(fast)

@@ -1,7 +1,7 @@
 """Operator-level drop-in for ``pytorch3d.renderer.mesh.rasterize_meshes`` as the reference reaches it through
 ``MeshRasterizer`` (/root/reference/environment.py:258-262, :276-280): the naive
 (``bin_size=0``) rasteriser with K-buffer outputs in PyTorch3D's layout, differentiable w.r.t. ``face_verts``
-through ``dists``.  ``OcclusionEnv.step`` does NOT go through here (it uses the fused ``occ_render``); this is for
+through ``dists``, ``zbuf`` and ``bary_coords``.  ``OcclusionEnv.step`` does NOT go through here (it uses the fused ``occ_render``); this is for
 callers of the rasteriser itself and for parity tests at that boundary.
 """
 from __future__ import annotations
@@ -40,7 +40,7 @@ class _RasterizeFaceVerts(torch.autograd.Function):
                      int(cull), _p(p2f), _p(zbuf), _p(bary), _p(dists), st), "occ_rasterize_meshes")
         ctx.save_for_backward(fv, p2f)
         ctx.cfg = (N, H, W, K, int(persp), int(clipb))
-        ctx.mark_non_differentiable(p2f, zbuf, bary)
+        ctx.mark_non_differentiable(p2f)
         ctx.set_materialize_grads(False)
         return p2f, zbuf, bary, dists
 
@@ -48,14 +48,18 @@ class _RasterizeFaceVerts(torch.autograd.Function):
     def backward(ctx, g_p2f, g_z, g_bary, g_dists):
         fv, p2f = ctx.saved_tensors
         N, H, W, K, persp, clipb = ctx.cfg
-        if g_dists is None:
+        if g_dists is None and g_z is None and g_bary is None:
             return (torch.zeros_like(fv),) + (None,) * 11
         lib = nat.load()
         gfv = torch.empty_like(fv)
         st = C.c_void_p(torch.cuda.current_stream(fv.device).cuda_stream)
-        nat.check(lib.occ_rasterize_meshes_backward_dists(_p(fv), _p(p2f), _p(g_dists.contiguous().float()), fv.shape[0], N, H,
-                                                          W, K, persp, clipb, _p(gfv), st),
-                  "occ_rasterize_meshes_backward_dists")
+
+        def c32(g):
+            return None if g is None else g.contiguous().float()
+
+        gz, gb, gd = c32(g_z), c32(g_bary), c32(g_dists)
+        nat.check(lib.occ_rasterize_meshes_backward(_p(fv), _p(p2f), _p(gz), _p(gb), _p(gd), fv.shape[0], N, H, W, K, persp,
+                                                    clipb, _p(gfv), st), "occ_rasterize_meshes_backward")
         return (gfv,) + (None,) * 11
 
 
