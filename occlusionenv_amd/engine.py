@@ -98,6 +98,8 @@ class OcclusionEngine:
         self._rec_tensors = None   # rec / rec_bbox / scan / rec_cbox / rec_off: sized by the records actually needed
         self._rec_total = 0
         self._mesh_host = np.zeros((NT, 3), dtype=np.int64)  # host copy of _mesh_all (kept current before every launch)
+        self._need_all = None        # cached _records_needed(_mesh_host) (see _put_mesh_rows)
+        self._scene_cache = None     # (key, OccScene) of the last whole-table scene struct
         self._faces_np = np.zeros(0, dtype=np.int64)
         self._faces_ver = -1
         self._reserve_cam_done = False
@@ -134,7 +136,7 @@ class OcclusionEngine:
             raise ValueError("mesh id outside the pool")
         self.scene_mesh[idx] = m.to(self.device)
         self.scene_offset[idx] = torch.as_tensor(offsets, dtype=torch.float32).reshape(-1, 3, 3).to(self.device)
-        self._mesh_host[np.asarray(env_ids, dtype=np.int64).reshape(-1)] = m.numpy()
+        self._put_mesh_rows(env_ids, m.numpy())
 
     # ---- workspace ------------------------------------------------------------------------
     def _scene_struct(self, n, scene_mesh, scene_offset, skip=None, pix_weight=None) -> nat.OccScene:
@@ -159,6 +161,25 @@ class OcclusionEngine:
             sc.pix_weight = pix_weight.data_ptr()
         return sc
 
+    def _put_mesh_rows(self, rows, mesh_ids) -> None:
+        """Write rows of the host copy of the scene mesh ids and keep the cached record need of the whole table
+        current (whole-batch launches ask for it every step: the sum is maintained, not recomputed)."""
+        rows = np.asarray(rows, dtype=np.int64).reshape(-1)
+        m = np.asarray(mesh_ids, dtype=np.int64).reshape(-1, 3)
+        if self._need_all is not None and self._faces_ver == self.pool.version and rows.size <= 64 \
+                and np.unique(rows).size == rows.size:
+            f_old = self._faces_np[self._mesh_host[rows].reshape(-1)]
+            f_new = self._faces_np[m.reshape(-1)]
+            self._need_all += int((((2 * f_new + 63) >> 6) << 6).sum() - (((2 * f_old + 63) >> 6) << 6).sum())
+        else:
+            self._need_all = None  # recomputed on demand
+        self._mesh_host[rows] = m
+
+    def _records_needed_all(self) -> int:
+        if self._need_all is None or self._faces_ver != self.pool.version:
+            self._need_all = self._records_needed(self._mesh_host)
+        return self._need_all
+
     def _rec_cap(self) -> int:
         # a z-clipped face can split in two (SURVEY A.3): worst case 2 records per face
         return 2 * max(self.pool.max_faces, 1)
@@ -174,12 +195,12 @@ class OcclusionEngine:
 
     def note_commit(self, env_id: int, slot: int) -> None:
         """The device installed reserve ``slot``'s scene in ``env_id`` (occ_auto_reset): keep the host copy current."""
-        self._mesh_host[env_id] = self._mesh_host[self.N + slot]
+        self._put_mesh_rows([env_id], self._mesh_host[self.N + slot].copy())
 
     def note_commits(self, env_ids, slots) -> None:
         """``note_commit`` for a batch (index arrays; an env takes at most one slot per step)."""
         if len(env_ids):
-            self._mesh_host[np.asarray(env_ids)] = self._mesh_host[self.N + np.asarray(slots)]
+            self._put_mesh_rows(env_ids, self._mesh_host[self.N + np.asarray(slots)].copy())
 
     def _ensure_workspace(self, need_records: Optional[int] = None) -> nat.OccWorkspace:
         """Fixed-size scratch (planes, K-buffers, ...) once; the record arrays hold ``rec_total`` records in a
@@ -212,7 +233,7 @@ class OcclusionEngine:
             self._ws, self._ws_tensors, self._ws_key = ws, t, key
             self._rec_tensors, self._rec_total = None, 0
         if need_records is None:
-            need_records = self._records_needed(self._mesh_host)
+            need_records = self._records_needed_all()
         if need_records > self._rec_total or self._rec_tensors is None:
             total = max(need_records, int(self._rec_total * 1.5), 64)
             total = ((total + 63) >> 6) << 6
@@ -366,7 +387,7 @@ class OcclusionEngine:
         c = torch.as_tensor(cand_ids, dtype=torch.long, device=self.device).reshape(-1)
         self.scene_mesh[e] = res["scene_mesh"][c]
         self.scene_offset[e] = res["scene_offset"][c]
-        self._mesh_host[np.asarray(env_ids, dtype=np.int64).reshape(-1)] = res["mesh_host"][np.asarray(cand_ids, dtype=np.int64).reshape(-1)]
+        self._put_mesh_rows(env_ids, res["mesh_host"][np.asarray(cand_ids, dtype=np.int64).reshape(-1)])
         self.radius[e] = res["radius"][c]
         self.azimuth[e] = res["azimuth"][c]
         self.elevation[e] = res["elevation"][c]
@@ -420,7 +441,7 @@ class OcclusionEngine:
             self._rs_off_host = torch.zeros(self.R, 3, 3, dtype=torch.float32).pin_memory()
         self._rs_mesh_host.numpy()[sl] = m
         self._rs_off_host.numpy()[sl] = off.reshape(n, 3, 3)
-        self._mesh_host[self.N + sl] = m
+        self._put_mesh_rows(self.N + sl, m)
         self._flip ^= 1
         host = self._refill_host[self._flip]
         h = host.numpy()
@@ -527,7 +548,11 @@ class OcclusionEngine:
         # pre_launch may have installed other scenes (auto-reset commits; the synchronous fallback reset may pick
         # larger models or grow the pool): size the record arrays and build the scene struct only now
         ws = self._ensure_workspace()
-        sc = self._scene_struct(NT, self._mesh_all, self._off_all, self._skip, pix_weight=pw)
+        # the scene struct of the whole table only changes with the pool, the shader or the weights: kept between steps
+        key = (self.pool.version, int(self.shader), None if pw is None else pw.data_ptr(), self._rec_cap())
+        if self._scene_cache is None or self._scene_cache[0] != key:
+            self._scene_cache = (key, self._scene_struct(NT, self._mesh_all, self._off_all, self._skip, pix_weight=pw))
+        sc = self._scene_cache[1]
         nat.check(self.lib.occ_camera(*cam_args), "occ_camera")
         if not self._reserve_cam_done:  # reset() camera of the reserve rows: radius 4, az = el = 0, never changes
             nat.check(self.lib.occ_camera(nat.CAM_LOOKAT, None, _p(self._el_all[N:]), _p(self._az_all[N:]),
