@@ -274,7 +274,10 @@ __global__ __launch_bounds__(1024) void occ_recoff_kernel(OccScene sc, long long
 // Objects with many visible faces (>= kSortMin records: a pixel then collects far more than K candidates) get
 // their scan order sorted front to back - bitonic sort of (depth key, record index) in LDS - so that the raster
 // kernel reaches "every pixel of the block holds its K nearest" after the nearest faces and skips the rest.
-constexpr int kSortMin = 4096;
+#ifndef OCC_SORT_MIN
+#define OCC_SORT_MIN 4096
+#endif
+constexpr int kSortMin = OCC_SORT_MIN;
 __global__ __launch_bounds__(256) void occ_sort_kernel(OccScene sc, OccWorkspace ws, int sort_cap) {
     extern __shared__ unsigned long long s_keys[];  // sort_cap keys: depth key << 32 | record index
     const int eo = blockIdx.x;

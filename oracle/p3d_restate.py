@@ -254,11 +254,12 @@ def rasterize_meshes(face_verts, S, blur_radius, K, cull_backfaces=True, z_clip=
     return p2f, zbuf, bary, dists
 
 
-def pixel_candidates(face_verts, S, yi, xi, blur_radius, band=1e-3, cull_backfaces=True, max_out=4096, area_band=2e-9):
+def pixel_candidates(face_verts, S, yi, xi, blur_radius, band=1e-3, cull_backfaces=True, max_out=4096, area_band=2e-9,
+                     vert_band=0.0):
     """Tie classifier support (tests/parity_utils.py): what the naive rasteriser computes at ONE pixel for every face
     that is a candidate there or misses by a hair (raster_naive.c: orc_pixel_candidates).  face_verts (F,3,3) AFTER
     clip_faces.  Returns dict of numpy arrays f, z, dist, minb, flags (1 inside, 2 candidate, 4 pz < 0, 8 = face area
-    within area_band of the kEpsilon visibility threshold)."""
+    within area_band + vert_band * perimeter of the kEpsilon visibility threshold)."""
     fv = face_verts.detach().to(torch.float32).contiguous()
     of = torch.empty(max_out, dtype=torch.int64)
     oz, od, ob = (torch.empty(max_out, dtype=torch.float32) for _ in range(3))
@@ -266,8 +267,8 @@ def pixel_candidates(face_verts, S, yi, xi, blur_radius, band=1e-3, cull_backfac
     fn = lib().orc_pixel_candidates_f32
     fn.restype = ctypes.c_int
     n = fn(_ptr(fv), ctypes.c_int64(fv.shape[0]), S, S, int(yi), int(xi), ctypes.c_float(blur_radius), 1,
-           int(blur_radius > 0.0), int(cull_backfaces), ctypes.c_float(band), ctypes.c_float(area_band), _ptr(of), _ptr(oz),
-           _ptr(od), _ptr(ob), _ptr(ofl), max_out)
+           int(blur_radius > 0.0), int(cull_backfaces), ctypes.c_float(band), ctypes.c_float(area_band),
+           ctypes.c_float(vert_band), _ptr(of), _ptr(oz), _ptr(od), _ptr(ob), _ptr(ofl), max_out)
     assert n >= 0
     return dict(f=of[:n].numpy(), z=oz[:n].numpy(), dist=od[:n].numpy(), minb=ob[:n].numpy(), flags=ofl[:n].numpy())
 

@@ -280,17 +280,17 @@ int FN(orc_rasterize_backward_dists)(const REAL* face_verts, const int64_t* pix_
 /*
  * Diagnostic for the parity tests' tie classifier (tests/parity_utils.py): everything the naive rasteriser
  * computes for ONE pixel, for every face that is a candidate there OR misses being one by a hair
- * (dist within blur*(1+band), bbox widened by the same relative band, signed area within area_band of the
- * kEpsilon visibility threshold).  No clipped-pair rule here (the classifier only asks how close a decision was).
+ * (dist within blur*(1+band), bbox widened by the same relative band, signed area within area_band + vert_band *
+ * perimeter of the kEpsilon visibility threshold: moving each vertex by <= vert_band moves the area by at most that).  No clipped-pair rule here (the classifier only asks how close a decision was).
  * Rows: f, z (pz), dist (unsigned), minb = smallest of the perspective-corrected barycentrics (the `inside` test is
  * minb > 0), flags: 1 = inside, 2 = candidate under the exact rule of orc_rasterize_naive, 4 = pz < 0,
- * 8 = the face's area is within area_band of kEpsilon (visible / culled by a hair; such a face is reported
+ * 8 = the face's area is within that band of kEpsilon (visible / culled by a hair; such a face is reported
  * whichever side it fell).  Returns the number of rows (<= max_out), -1 on bad args.
  */
 int FN(orc_pixel_candidates)(const REAL* face_verts, int64_t F, int H, int W, int yi, int xi, REAL blur_radius,
                              int perspective_correct, int clip_barycentric, int cull_backfaces, REAL band,
-                             REAL area_band, int64_t* out_f, REAL* out_z, REAL* out_dist, REAL* out_minb,
-                             int32_t* out_flags, int max_out) {
+                             REAL area_band, REAL vert_band, int64_t* out_f, REAL* out_z, REAL* out_dist,
+                             REAL* out_minb, int32_t* out_flags, int max_out) {
     if (!face_verts || yi < 0 || yi >= H || xi < 0 || xi >= W || max_out <= 0) return -1;
     const REAL sq_blur = (REAL)sqrt((double)blur_radius);
     const REAL sq_wide = (REAL)sqrt((double)(blur_radius * ((REAL)1 + band))) + (REAL)1e-6;
@@ -303,9 +303,13 @@ int FN(orc_pixel_candidates)(const REAL* face_verts, int64_t F, int H, int W, in
         const v2 v0 = {fv[0], fv[1]}, v1 = {fv[3], fv[4]}, v2_ = {fv[6], fv[7]};
         const REAL z0 = fv[2], z1 = fv[5], z2 = fv[8];
         const REAL area = edge_fn(v0, v1, v2_);
-        const int hair = cull_backfaces ? (area > kEpsilon - area_band && area < kEpsilon + area_band)
-                                        : ((area > kEpsilon - area_band && area < kEpsilon + area_band) ||
-                                           (-area > kEpsilon - area_band && -area < kEpsilon + area_band));
+        const double perim = sqrt((double)((v1.x - v0.x) * (v1.x - v0.x) + (v1.y - v0.y) * (v1.y - v0.y))) +
+                             sqrt((double)((v2_.x - v1.x) * (v2_.x - v1.x) + (v2_.y - v1.y) * (v2_.y - v1.y))) +
+                             sqrt((double)((v0.x - v2_.x) * (v0.x - v2_.x) + (v0.y - v2_.y) * (v0.y - v2_.y)));
+        const REAL ab = area_band + vert_band * (REAL)perim;
+        const int hair = cull_backfaces ? (area > kEpsilon - ab && area < kEpsilon + ab)
+                                        : ((area > kEpsilon - ab && area < kEpsilon + ab) ||
+                                           (-area > kEpsilon - ab && -area < kEpsilon + ab));
         const int visible = !(cull_backfaces && area < 0) && !(area <= kEpsilon && area >= -kEpsilon);
         if (!visible && !hair) continue;
         if (rmax(rmax(z0, z1), z2) < 0) continue;

@@ -51,3 +51,10 @@ for seed in map(int, sys.argv[1:]):
             ins = (pc["flags"] & 1) != 0
             zi = np.sort(pc["z"][ins])
             print("    inside depths:", zi[:5], " gpu obs", got["obs0" if phase == "reset" else "obs"][i][:, y, x].tolist())
+            ob = env.reset(radius=c["radius"], azimuth=float(case["az"][i])) if phase == "reset" else None
+            if ob is not None:
+                print("    oracle obs", ob.reshape(4, S, S)[:, y, x].tolist())
+            for j in np.nonzero(ins)[0][np.argsort(pc["z"][ins])][:3]:
+                ff = int(pc["f"][j]); v = fv[ff].detach().numpy().astype(np.float64)
+                e = [float(np.hypot(*(v[(k + 1) % 3, :2] - v[k, :2]))) for k in range(3)]
+                print("    inside face %d: z %.7f minb %.3e area %.4e edges %s zs %s" % (ff, pc["z"][j], pc["minb"][j], float(area[ff]), np.round(e, 5).tolist(), v[:, 2].round(5).tolist()))

@@ -333,12 +333,42 @@ def test_tie_classifier_bands_are_frozen():
     tightened, never loosened, without this test being changed on purpose."""
     from tests import parity_utils as pu
 
-    frozen = dict(TOL=1e-4, TZ_REL=1e-6, TB_REL=1e-4, TPAIR_REL=1e-4, TEDGE=5e-7, TAREA=2e-9, TTEXEL=1e-3,
+    frozen = dict(TOL=1e-4, TZ_REL=1e-6, TB_REL=1e-4, TPAIR_REL=1e-4, TEDGE=5e-7, TAREA=2e-9, TVERT=2.5e-7, TTEXEL=1e-3,
                   GRAD_NOISE_ULPS=256.0)
     for name, bound in frozen.items():
         assert 0 < getattr(pu, name) <= bound, (name, getattr(pu, name), bound)
     for img in (64, 128, 256, 512):
         assert pu.max_tie_pixels(img) <= max(4, int(2e-4 * img * img * 3))
+
+
+def test_hair_band_scales_with_the_perimeter_and_needle_depth_bound():
+    """The two conditioning rules of the classifier on the faces that motivated them (parity sweep seeds 2352, 2084):
+    a needle's area moves by vertex noise x perimeter, its barycentrics by that / area."""
+    from oracle import p3d_restate as O
+    from tests import parity_utils as pu
+
+    # like seed 2352, object 1, face 664 (signed area 7.5e-9: culled by the oracle, kept by the engine at 1.3e-8;
+    # perimeter 0.18): a needle 0.09 long and 8e-8 high
+    fv = torch.tensor([[[0.02, 0.0, 2.22], [0.11, 0.0, 2.23], [0.065, -8.33e-8, 2.21]]])
+    x, y = fv[0, :, 0].double(), fv[0, :, 1].double()
+    area = float((x[2] - x[0]) * (y[1] - y[0]) - (y[2] - y[0]) * (x[1] - x[0]))
+    assert 7e-9 < area < 8e-9 and abs(area - 1e-8) > pu.TAREA
+    S, yi, xi = 64, 31, 30
+    plain = O.pixel_candidates(fv, S, yi, xi, O.BLUR_RADIUS, band=1e-3, area_band=pu.TAREA)
+    wide = O.pixel_candidates(fv, S, yi, xi, O.BLUR_RADIUS, band=1e-3, area_band=pu.TAREA, vert_band=pu.TVERT)
+    assert plain["f"].size == 0  # culled, and not within the plain band
+    assert wide["f"].size == 1 and (wide["flags"] & 8).all()
+    # a compact face of the same area class is NOT given the wide band: perimeter 3e-4 adds 7.5e-11
+    small = torch.tensor([[[0.0, 0.0, 2.0], [0.0, 1e-4, 2.0], [-1.3e-4, 0.0, 2.0]]])
+    c = O.pixel_candidates(small, S, 32, 32, O.BLUR_RADIUS, band=1e-3, area_band=pu.TAREA, vert_band=pu.TVERT)
+    assert not (c["flags"] & 8).any()
+    # seed 2084, scene face 5797: area 1.05e-5, edges 0.159 / 0.095 / 0.064, depth range 0.106 -> bound ~1.6e-3;
+    # an ordinary face (area 1e-3, edges 0.05) stays far below TOL
+    needle = np.array([[0.0, 0.0, 1.566], [0.159, 0.0, 1.488], [0.095, 6.6e-5, 1.459]])
+    b = pu.sliver_depth_bound(needle)
+    assert 5e-4 < b < 5e-3
+    fat = np.array([[0.0, 0.0, 1.5], [0.05, 0.0, 1.52], [0.0, 0.04, 1.48]])
+    assert pu.sliver_depth_bound(fat) < 0.05 * pu.TOL
 
 
 def test_pool_keys_survive_dataset_address_reuse():
