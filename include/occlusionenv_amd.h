@@ -114,7 +114,7 @@ typedef struct OccScene {
 /* Caller-allocated scratch; sizes from occ_workspace_query(). */
 typedef struct OccWorkspace {
     float* rec;         /* (n_env,3,rec_cap,OCC_REC_STRIDE) projected face records */
-    uint32_t* rec_bbox; /* (n_env,3,rec_cap,4) per record: pixel bbox xl|yl<<16, xh|yh<<16, key of its nearest vertex depth, flat-shading ambient+diffuse (f32 bits) */
+    uint32_t* rec_bbox; /* (n_env,3,rec_cap,4) per record: pixel bbox xl|yl<<16, xh|yh<<16|corner-cut bits<<28 (img <= 2048), key of its nearest vertex depth, flat-shading ambient+diffuse (f32 bits) */
     uint32_t* scan;     /* (n_env,3,rec_cap,4) the same rows sorted front to back, .w = record index (the raster scan order) */
     int32_t* nrec;      /* (n_env,3) */
     int32_t* objrect;   /* (n_env,3,4) block rect bx0,by0,bx1,by1 (inclusive, OCC_BLOCK-pixel units) */

@@ -7,7 +7,8 @@
 //
 //   * LANE = (face, pixel) PAIR.  For every staged face the wave enumerates exactly the pixels of the face's pixel
 //     bbox (setup kernel, +-sqrt(blur)) that fall into the tile - about 10 per ShapeNet-size face and tile, of which
-//     68 % turn out to be candidates (round 1: 64 lane-evaluations per (face, block), 26 % useful).  Every face marks
+//     68 % turn out to be candidates (round 1: 64 lane-evaluations per (face, block), 26 % useful) - minus the box corners
+//     that the setup kernel marked as beyond the blur disc (finish_tri: corner cut; 76 % candidates).  Every face marks
 //     its first pair in a byte map built from a wave prefix sum over the faces' pair counts; a round of the loop
 //     evaluates 64 consecutive pairs (face = running count + marks at or below the lane, pixel = first + jj +
 //     row (8 - width) from one multiply by 2^15 / width), each lane reading ITS face's record from an LDS image of the
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
         const bool dense = n >= kSortMin;
 
         auto touches = [&](uint4 bb) {
-            const int rx0 = bb.x & 0xFFFF, ry0 = bb.x >> 16, rx1 = bb.y & 0xFFFF, ry1 = bb.y >> 16;
+            const int rx0 = bb.x & 0xFFFF, ry0 = bb.x >> 16, rx1 = bb.y & 0xFFFF, ry1 = (bb.y >> 16) & 0x0FFF;  // (corner-cut bits above)
             return (rx0 <= x0t + kT2 - 1) && (rx1 >= x0t) && (ry0 <= y0t + kT2 - 1) && (ry1 >= y0t);
         };
         // this lane's pixel: candidates held and their largest key (four copies folded)
@@ -661,13 +662,30 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             wave_lds_sync();
             // pixels of this lane's face inside the tile: pair count, prefix sum over the staged faces
             int c = 0, cx0 = 0, cy0 = 0, cw = 1;
+            // corner cut (finish_tri): which corners of the face's pixel box fall into this item's part of it and are
+            // marked as beyond the blur disc.  The pairs of the box are numbered row by row; e0 drops number 0, thrA /
+            // thrB are the numbers (counted with e0 already skipped) from which one / two more are skipped (127: never).
+            uint32_t e0 = 0u, thrA = 127u, thrB2 = 127u;
             if (lane < nst) {
                 const uint2 bb = s_box[boff + lane];
-                cx0 = max((int)(bb.x & 0xFFFFu), x0t);
-                cy0 = max((int)(bb.x >> 16), y0t + row_lo);
-                const int cx1 = min((int)(bb.y & 0xFFFFu), x0t + kT2 - 1), cy1 = min((int)(bb.y >> 16), y0t + row_hi);
+                const int bxl = (int)(bb.x & 0xFFFFu), byl = (int)(bb.x >> 16), bxh = (int)(bb.y & 0xFFFFu), byh = (int)((bb.y >> 16) & 0x0FFFu);
+                cx0 = max(bxl, x0t);
+                cy0 = max(byl, y0t + row_lo);
+                const int cx1 = min(bxh, x0t + kT2 - 1), cy1 = min(byh, y0t + row_hi);
                 cw = cx1 - cx0 + 1;
-                c = max(cw, 0) * max(cy1 - cy0 + 1, 0);
+                const int ch = cy1 - cy0 + 1;
+                c = max(cw, 0) * max(ch, 0);
+                if (c > 0) {
+                    const uint32_t cb = bb.y >> 28;
+                    const bool left = cx0 == bxl, right = cx1 == bxh, top = cy0 == byl, bot = cy1 == byh;
+                    e0 = ((cb & 1u) && left && top) ? 1u : 0u;
+                    const uint32_t e1 = ((cb & 2u) && right && top && cw > 1) ? 1u : 0u;
+                    const uint32_t e2 = ((cb & 4u) && left && bot && ch > 1) ? 1u : 0u;
+                    const uint32_t e3 = ((cb & 8u) && right && bot && cw > 1 && ch > 1) ? 1u : 0u;
+                    if (e1) thrA = (uint32_t)(cw - 1);
+                    if (e2) thrB2 = (uint32_t)((ch - 1) * cw) - e1;
+                    c -= (int)(e0 + e1 + e2 + e3);
+                }
                 cw = max(cw, 1);
             }
             // exclusive prefix sum of the pair counts (<= 64 each: 7 bits) from one ballot per bit - no LDS round trips
@@ -694,8 +712,11 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 if (has) {
                     const uint32_t inv15 = (32768u + (uint32_t)cw - 1u) / (uint32_t)cw;
                     // geometry word: pixel of the face's first pair (6 bits), 8 - width (3 bits, 0..7), staged slot, 2^15 / width
-                    s_box[boff + r] = make_uint2((uint32_t)pre, (uint32_t)(cx0 - x0t) | ((uint32_t)(cy0 - y0t) << 3) | ((uint32_t)(8 - cw) << 6) |
-                                                                    ((uint32_t)lane << 9) | (inv15 << 16));
+                    // .x: number of the face's first pair in the batch (minus e0: a lane's pair number minus this, mod 2^16, is
+                    // its number in the face's box with the first corner skipped) | thrA << 16 | thrB << 24
+                    s_box[boff + r] = make_uint2(((uint32_t)(pre - (int)e0) & 0xFFFFu) | (thrA << 16) | (thrB2 << 24),
+                                                 (uint32_t)(cx0 - x0t) | ((uint32_t)(cy0 - y0t) << 3) | ((uint32_t)(8 - cw) << 6) |
+                                                     ((uint32_t)lane << 9) | (inv15 << 16));
                     if (r > 0) s_flag[pre] = 1;
                 }
             };
@@ -760,9 +781,11 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     fbase += __popcll(mk);
                     const uint2 fg = s_box[boff + fr];
                     dc.f = (int)((fg.y >> 9) & 31u);  // its staged slot
-                    const uint32_t jj = (uint32_t)(p0 + lane) - fg.x;
+                    // number of the pair in the face's box: skipped corners (corner cut) are stepped over
+                    const uint32_t j1 = ((uint32_t)(p0 + lane) - fg.x) & 0xFFFFu;
+                    const uint32_t jj = j1 + (j1 >= ((fg.x >> 16) & 0xFFu) ? 1u : 0u) + (j1 >= (fg.x >> 24) ? 1u : 0u);
                     // row = jj / width, column = jj - row * width: pixel = first + 8 row + column = first + jj + row (8 - width)
-                    // (exact for jj < 64, width <= 8); 24-bit multiplies: full rate (v_mul_lo_u32 is quarter rate)
+                    // (exact for jj < 64, width <= 8; lanes past the last pair may hold more - masked below); 24-bit multiplies: full rate (v_mul_lo_u32 is quarter rate)
                     const uint32_t wq = mul24(jj, fg.y >> 16) >> 15;
                     const uint32_t d = ((fg.y & 63u) + jj + mul24(wq, (fg.y >> 6) & 7u)) & 63u;
                     dc.pix = (int)d;

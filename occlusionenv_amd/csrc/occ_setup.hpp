@@ -65,7 +65,8 @@ __device__ __forceinline__ PVert cut_edge(const VVert& a, const VVert& b) {
 
 struct Tri {
     PVert v[3];
-    uint4 bbox;  // conservative pixel bbox x = xl | yl << 16, y = xh | yh << 16; z = key of the smallest vertex depth
+    uint4 bbox;  // conservative pixel bbox x = xl | yl << 16, y = xh | yh << 16 | corner-cut bits << 28 (finish_tri; pixel
+                 // coordinates are < 2048); z = key of the smallest vertex depth
     int tx0, ty0, tx1, ty1;
 };
 
@@ -99,8 +100,28 @@ __device__ __forceinline__ bool finish_tri(Tri& t, int S) {
     t.tx1 = xh / OCC_BLOCK;
     t.ty0 = yl / OCC_BLOCK;
     t.ty1 = yh / OCC_BLOCK;
+    // CORNER CUT: the pixel box of a small face is the face's own box grown by sqrt(blur) on every side - a rounded
+    // square, of which the blur disc leaves corner pixels out.  A corner pixel whose centre is farther than sqrt(blur)
+    // from the face's OWN box is farther than that from the triangle inside it: it can neither be inside nor within
+    // the blur radius (relative margin 1e-3 on the squared distance against the rounding of either side).  Bits 28..31
+    // of bbox.y: corner (xl, yl), (xh, yl), (xl, yh), (xh, yh) can be skipped; occ_raster2_kernel leaves those (face,
+    // pixel) pairs out of its rounds (6 % of the rounds of the bench's sub-pixel faces; the exact point-triangle
+    // distance per corner finds 2 % more and costs the setup kernel 0.6 ms: measured, not kept).
+    uint32_t corner = 0u;
+#ifndef OCC_NO_CORNER_CUT  // (the A/B build of tests/test_gpu_parity.py: results must not change by a bit)
+    {
+        auto ctr = [&](int i) { return -1.0f + (2.0f * (float)(S - 1 - i) + 1.0f) / fS; };  // pixel centre, as the raster kernel
+        auto gap = [](float lo, float hi, float c) { return fmaxf(fmaxf(lo - c, c - hi), 0.0f); };
+        const float fx0 = fmin3(x0, x1, x2), fx1 = fmax3(x0, x1, x2), fy0 = fmin3(y0, y1, y2), fy1 = fmax3(y0, y1, y2);
+        const float gxl = gap(fx0, fx1, ctr(xl)), gxh = gap(fx0, fx1, ctr(xh));
+        const float gyl = gap(fy0, fy1, ctr(yl)), gyh = gap(fy0, fy1, ctr(yh));
+        const float lim2 = kBlurRadius * 1.001f;
+        corner = (gxl * gxl + gyl * gyl > lim2 ? 1u : 0u) | (gxh * gxh + gyl * gyl > lim2 ? 2u : 0u) |
+                 (gxl * gxl + gyh * gyh > lim2 ? 4u : 0u) | (gxh * gxh + gyh * gyh > lim2 ? 8u : 0u);
+    }
+#endif
     const uint32_t zb = __float_as_uint(fmin3(t.v[0].z, t.v[1].z, t.v[2].z));
-    t.bbox = make_uint4((uint32_t)xl | ((uint32_t)yl << 16), (uint32_t)xh | ((uint32_t)yh << 16),
+    t.bbox = make_uint4((uint32_t)xl | ((uint32_t)yl << 16), (uint32_t)xh | ((uint32_t)yh << 16) | (corner << 28),
                         (zb & 0x80000000u) ? ~zb : (zb | 0x80000000u), 0u);
     return vis;
 }
@@ -178,7 +199,7 @@ __device__ __forceinline__ void chunk_boxes(const uint4* __restrict__ scan, uint
         const int j = c * 64 + lane;
         uint4 bb = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
         if (j < nr) bb = scan[j];
-        int xl = bb.x & 0xFFFF, yl = bb.x >> 16, xh = bb.y & 0xFFFF, yh = bb.y >> 16;
+        int xl = bb.x & 0xFFFF, yl = bb.x >> 16, xh = bb.y & 0xFFFF, yh = (bb.y >> 16) & 0x0FFF;  // (corner-cut bits above)
         uint32_t zk = bb.z;
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
@@ -567,7 +588,7 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
                         tri.tx0 = (int)(bx.x & 0xFFFFu) / OCC_BLOCK;
                         tri.ty0 = (int)(bx.x >> 16) / OCC_BLOCK;
                         tri.tx1 = (int)(bx.y & 0xFFFFu) / OCC_BLOCK;
-                        tri.ty1 = (int)(bx.y >> 16) / OCC_BLOCK;
+                        tri.ty1 = (int)((bx.y >> 16) & 0x0FFFu) / OCC_BLOCK;
                     }
                     auto emit = [&](float* __restrict__ r) {
                         write_record<false>(r, bbs + pos, scan + pos, pos, tri, f, 0, sh);

@@ -604,7 +604,7 @@ def test_work_item_order_is_a_cost_sorted_permutation_of_all_tiles(mesh, S):
     for k in np.random.default_rng(0).choice(len(items), size=min(400, len(items)), replace=False).tolist():
         eo, (tx, ty) = int(eos[k]), expect[(int(eos[k]), int(local[k]))]
         bb = bbox[rec_off[eo]: rec_off[eo] + nrec[eo]]
-        xl, yl, xh, yh = bb[:, 0] & 0xFFFF, bb[:, 0] >> 16, bb[:, 1] & 0xFFFF, bb[:, 1] >> 16
+        xl, yl, xh, yh = bb[:, 0] & 0xFFFF, bb[:, 0] >> 16, bb[:, 1] & 0xFFFF, (bb[:, 1] >> 16) & 0x0FFF  # (corner-cut bits above)
         touching = int(np.count_nonzero((xl <= tx * 8 + 7) & (xh >= tx * 8) & (yl <= ty * 8 + 7) & (yh >= ty * 8)))
         assert touching < bound(int(cls[k])), (eo, tx, ty, touching, int(cls[k]))
 

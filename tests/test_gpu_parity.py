@@ -141,6 +141,37 @@ def test_small_log_build_forces_inloop_compaction():
     _check(json.loads(line[3:]))
 
 
+def test_corner_cut_never_changes_a_bit():
+    """The setup kernel marks corner pixels of a face's pixel box that lie beyond the blur disc of the face's own box
+    (occ_setup.hpp: finish_tri) and the raster kernel leaves those (face, pixel) pairs out of its rounds.  They were
+    never candidates: every output of a step equals, bit for bit, what the build without the cut computes (on scenes
+    whose tiles stay below the log capacity: an in-loop compaction, triggered by the pair count, regroups the sums)."""
+    import tempfile
+
+    from tests.parity_utils import make_case, run_engine
+
+    lib = os.path.join(ROOT, "occlusionenv_amd", "libocc_hip_nocut.so")
+    assert os.path.exists(lib), "run __graft_entry__.build() first"
+    cases = [(2, 64, 5, "teapot", 4.0), (3, 128, 6, "synthetic", 4.0), (2, 64, 7, "mixed", 4.0), (2, 96, 8, "textured", 1.3)]
+    keys = ("obs0", "alphas0", "obs", "alphas", "fs", "loss", "reward", "grad")
+    with tempfile.TemporaryDirectory() as td:
+        out_path = os.path.join(td, "nocut.pt")
+        code = ("import sys, torch; sys.path.insert(0, %r); from tests.parity_utils import make_case, run_engine\n"
+                "res = []\n"
+                "for n, img, seed, mesh, radius in %r:\n"
+                "    got = run_engine(make_case(n, seed, mesh), img, radius=radius)\n"
+                "    res.append({k: got[k].detach().cpu() for k in %r})\n"
+                "torch.save(res, %r)\n" % (ROOT, cases, keys, out_path))
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OCC_HIP_LIB=lib), capture_output=True,
+                             text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        ref = torch.load(out_path)
+    for (n, img, seed, mesh, radius), r in zip(cases, ref):
+        got = run_engine(make_case(n, seed, mesh), img, radius=radius)
+        for k in keys:
+            assert torch.equal(got[k].detach().cpu(), r[k]), (mesh, img, k)
+
+
 def test_multi_step_trajectory_matches_oracle():
     """State carried across steps (el/az accumulation, fullReward hand-over, environment.py:354-392): five steps of a
     gradient-ascent trajectory (demo.py:80-114) driven by the oracle's gradients, same actions on both sides.  The
