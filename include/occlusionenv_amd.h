@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define OCC_ABI_VERSION 6
+#define OCC_ABI_VERSION 7
 
 /* return codes */
 #define OCC_OK 0
@@ -254,6 +254,29 @@ int occ_sigmoid_alpha_blend_fwd(const float* dists, const int64_t* pix_to_face, 
                                 float sigma, float* images, void* stream);
 int occ_sigmoid_alpha_blend_bwd(const float* dists, const int64_t* pix_to_face, const float* grad_images, int64_t n_pix,
                                 int faces_per_pixel, float sigma, float* grad_dists, void* stream);
+
+/*
+ * The K epochs of PPO.update (PPO.py:196-217) for the heads-only learner of the vectorised env: the reference optimises
+ * action_head (256 -> 2) and value_head (256 -> 1) only (PPO.py:113-116; model.py:153-154,168-171 detaches the features),
+ * with the fixed diagonal Gaussian of ActorCritic (PPO.py:62-104) and torch.optim.Adam.  ONE launch per epoch: forward,
+ * clipped-surrogate loss, backward and the Adam step over the 771 parameters; parameters, moments and step count are
+ * updated in place.  feats (M,256), actions (M,2), old_logprob (M), returns (M) [already normalised, PPO.py:187-188];
+ * losses (n_epochs,2) receives (total loss, value loss) of every epoch; scratch: OCC_PPO_SCRATCH_FLOATS floats;
+ * counter: one zeroed uint32 (left at zero).  Adam moments m, v: 771 floats each in the order W_a | b_a | W_v | b_v.
+ */
+#define OCC_PPO_FEATURES 256
+#define OCC_PPO_PARAMS (3 * OCC_PPO_FEATURES + 3)
+#define OCC_PPO_MAX_BLOCKS 64
+#define OCC_PPO_SCRATCH_FLOATS (OCC_PPO_MAX_BLOCKS * (OCC_PPO_PARAMS + 2))
+typedef struct OccPpoState {
+    float *w_a, *b_a, *w_v, *b_v; /* action_head.weight (2,256), .bias (2), value_head.weight (1,256), .bias (1) */
+    float *adam_m, *adam_v;       /* OCC_PPO_PARAMS each */
+    float* adam_step;             /* (1) step count as float (torch's capturable Adam keeps it on the device too) */
+} OccPpoState;
+int occ_ppo_update(const float* feats, const float* actions, const float* old_logprob, const float* returns, int64_t M,
+                   float action_var, float eps_clip, float lr_actor, float lr_critic, float beta1, float beta2,
+                   float adam_eps, const OccPpoState* state, int n_epochs, float* losses, float* scratch,
+                   uint32_t* counter, void* stream);
 
 /*
  * Host hand-off of SimpleVecEnv.step_wait (SubProcVecEnv.py:209-218): one int32 buffer

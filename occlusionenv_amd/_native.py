@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OCC_HIP_LIB") or os.path.join(_HERE, "libocc_hip.so")
 
 # layout constants (must match include/occlusionenv_amd.h)
-ABI_VERSION = 6
+ABI_VERSION = 7
 CAM_STRIDE = 48
 REC_STRIDE = 32
 TILE = 8
@@ -113,6 +113,16 @@ class OccEnvState(C.Structure):
                                           "scene_mesh", "scene_offset")]
 
 
+class OccPpoState(C.Structure):
+    """include/occlusionenv_amd.h: OccPpoState (parameters, Adam moments and step count of the heads-only learner)."""
+    _fields_ = [(n, C.c_void_p) for n in ("w_a", "b_a", "w_v", "b_v", "adam_m", "adam_v", "adam_step")]
+
+
+PPO_FEATURES = 256
+PPO_PARAMS = 3 * PPO_FEATURES + 3
+PPO_SCRATCH_FLOATS = 64 * (PPO_PARAMS + 2)
+
+
 class OccReserveStore(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("obs", "full_state", "loss", "skip")]
 
@@ -141,6 +151,8 @@ SYMBOLS = {
     "occ_sigmoid_alpha_blend_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "occ_sigmoid_alpha_blend_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p,
                                               C.c_void_p]),
+    "occ_ppo_update": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 7 + [C.POINTER(OccPpoState), C.c_int, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "occ_step_flags": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "occ_reset_commit": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 13 + [C.c_int, C.c_void_p]),
     "occ_auto_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -48,6 +48,7 @@ namespace occ {
 #include "occ_blend.hpp"
 #include "occ_reset.hpp"
 #include "occ_oplevel.hpp"
+#include "occ_ppo.hpp"
 
 }  // namespace occ
 
@@ -395,6 +396,37 @@ extern "C" int occ_sigmoid_alpha_blend_bwd(const float* dists, const int64_t* pi
         return OCC_ERR_ARG;
     hipLaunchKernelGGL(occ_blend_bwd_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dists,
                        pix_to_face, grad_images, (long)n_pix, faces_per_pixel, sigma, grad_dists);
+    return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
+}
+
+extern "C" int occ_ppo_update(const float* feats, const float* actions, const float* old_logprob, const float* returns,
+                              int64_t M, float action_var, float eps_clip, float lr_actor, float lr_critic, float beta1,
+                              float beta2, float adam_eps, const OccPpoState* state, int n_epochs, float* losses,
+                              float* scratch, uint32_t* counter, void* stream) {
+    static_assert(kPpoFeat == OCC_PPO_FEATURES && kPpoParams == OCC_PPO_PARAMS, "occ_ppo.hpp and the header disagree");
+    if (!feats || !actions || !old_logprob || !returns || M <= 0 || !(action_var > 0.f) || !state || n_epochs < 0 || !losses ||
+        !scratch || !counter || !state->w_a || !state->b_a || !state->w_v || !state->b_v || !state->adam_m || !state->adam_v ||
+        !state->adam_step)
+        return OCC_ERR_ARG;
+    PpoArgs A;
+    A.feats = feats; A.actions = actions; A.old_lp = old_logprob; A.returns = returns; A.M = (long long)M;
+    A.inv_var = 1.0f / action_var;
+    // MultivariateNormal(mean, var I) in two dimensions: log-density constant and entropy (PPO.py:62-104)
+    const float log2pi = 1.8378770664093453f, logdet = 2.0f * logf(action_var);
+    A.lp_const = -0.5f * (2.0f * log2pi + logdet);
+    A.ent_term = 0.01f * 0.5f * (2.0f * (1.0f + log2pi) + logdet);
+    A.eps_clip = eps_clip;
+    A.lr_actor = lr_actor; A.lr_critic = lr_critic; A.beta1 = beta1; A.beta2 = beta2; A.adam_eps = adam_eps;
+    A.w_a = state->w_a; A.b_a = state->b_a; A.w_v = state->w_v; A.b_v = state->b_v;
+    A.m = state->adam_m; A.v = state->adam_v; A.step = state->adam_step;
+    A.partials = scratch; A.counter = counter;
+    // a wave takes ~12 samples of a 10^4-sample rollout: 64 blocks of 16 waves; few rows for the last block's sum
+    const long long want = (M + 16 * 8 - 1) / (16 * 8);
+    const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > OCC_PPO_MAX_BLOCKS ? OCC_PPO_MAX_BLOCKS : want));
+    for (int e = 0; e < n_epochs; ++e) {
+        A.losses = losses + 2 * e;
+        hipLaunchKernelGGL(occ_ppo_epoch_kernel, dim3(blocks), dim3(kPpoThreads), 0, (hipStream_t)stream, A);
+    }
     return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
 }
 

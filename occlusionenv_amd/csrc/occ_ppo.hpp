@@ -1,0 +1,149 @@
+// occ_ppo.hpp -- one PPO epoch of the heads-only learner as ONE kernel (config 5: the update of the rollout loop).
+// Part of the single translation unit occ_kernels.hip (included inside namespace occ; not a stand-alone header).
+//
+// The reference optimises the ACTION and VALUE heads only (PPO.py:113-116; FullNetwork.act detaches the features,
+// model.py:168-171): per epoch (PPO.py:196-217) two 256 -> 2 / 256 -> 1 linear layers over the M = T * N samples of the
+// rollout, the clipped surrogate, its backward and an Adam step over 771 parameters.  As framework ops that is ~35
+// launches of a few microseconds each per epoch (80 epochs: 35 ms per update even as replays of a captured graph, a fifth
+// of config 5's step time); as arithmetic it is one pass over 13 MB of features.  Here: every wave takes samples in a
+// strided loop - the lane holds 4 of the 256 features (one 16-byte load per sample, the three weight rows in registers),
+// three wave reductions give (mean_0, mean_1, value), every lane then forms the sample's loss terms and output
+// gradients and adds its share of the weight gradients in registers.  Blocks write their partial sums to scratch; the
+// LAST block to arrive (device-scope counter) adds the partials in block order - a fixed summation order, results are
+// reproducible - applies Adam and writes the epoch's two loss values.  The next epoch is the next launch on the stream.
+//
+// Formulas (fixed diagonal Gaussian of ActorCritic, PPO.py:62-104; loss PPO.py:199-212; torch.optim.Adam):
+//   lp = -0.5 sum_j (a_j - mean_j)^2 / var - 0.5 (2 log 2 pi + 2 log var);  ratio = exp(lp - lp_old);  adv = ret - value
+//   loss = mean(-min(ratio adv, clamp(ratio, 1 - c, 1 + c) adv)) + 0.5 mean((value - ret)^2) - 0.01 entropy
+//   d loss / d mean_j = -[unclipped or surr1 < surr2] adv ratio (a_j - mean_j) / (var M)     (torch.min splits a tie evenly
+//   between two equal branches with equal derivatives);  d loss / d value = (value - ret) / M;  the entropy is constant.
+//   Adam: m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2; p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).
+
+constexpr int kPpoFeat = 256;                      // features per sample (FullNetwork's pooled encoder output)
+constexpr int kPpoParams = 3 * kPpoFeat + 3;       // W_a (2,256) | b_a (2) | W_v (1,256) | b_v (1): the layout of OccPpoState
+constexpr int kPpoPartial = kPpoParams + 2;        // + (sum of -min(surr1, surr2), sum of (value - ret)^2)
+constexpr int kPpoThreads = 1024;                 // 16 waves per block: few blocks = few rows for the last block's sum
+constexpr int kPpoRow = (kPpoPartial + 3) & ~3;  // LDS row of a wave's sums: 16-byte aligned for the float4 stores
+
+struct PpoArgs {
+    const float* feats;     // (M, 256)
+    const float* actions;   // (M, 2)
+    const float* old_lp;    // (M)
+    const float* returns;   // (M) normalised returns
+    long long M;
+    float inv_var, lp_const, eps_clip, ent_term;  // 1 / action variance; -0.5 (2 log 2 pi + log det); clip; 0.01 * entropy
+    float lr_actor, lr_critic, beta1, beta2, adam_eps;
+    float* w_a;  float* b_a;  float* w_v;  float* b_v;       // parameters (updated in place)
+    float* m;    float* v;                                   // Adam moments, kPpoParams each, parameter layout above
+    float* step;                                             // (1) Adam step count (float, like torch's capturable Adam)
+    float* partials;                                         // (gridDim.x, kPpoPartial) scratch
+    unsigned int* counter;                                   // (1) zero before the first launch; left at zero
+    float* losses;                                           // (2) this epoch's (loss, value loss)
+};
+
+__global__ __launch_bounds__(kPpoThreads) void occ_ppo_epoch_kernel(PpoArgs A) {
+    __shared__ __attribute__((aligned(16))) float s_part[kPpoThreads / 64][kPpoRow];
+    __shared__ bool s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float4 wa0 = reinterpret_cast<const float4*>(A.w_a)[lane];
+    const float4 wa1 = reinterpret_cast<const float4*>(A.w_a + kPpoFeat)[lane];
+    const float4 wv = reinterpret_cast<const float4*>(A.w_v)[lane];
+    const float ba0 = A.b_a[0], ba1 = A.b_a[1], bv = A.b_v[0];
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, gv = g0;
+    float gb0 = 0.f, gb1 = 0.f, gbv = 0.f, lsum = 0.f, vsum = 0.f;
+    const float invM = 1.0f / (float)A.M;
+    const long long stride = (long long)gridDim.x * (kPpoThreads / 64);
+    for (long long i = (long long)blockIdx.x * (kPpoThreads / 64) + wave; i < A.M; i += stride) {
+        const float4 f = reinterpret_cast<const float4*>(A.feats + i * kPpoFeat)[lane];
+        float d0 = f.x * wa0.x + f.y * wa0.y + f.z * wa0.z + f.w * wa0.w;
+        float d1 = f.x * wa1.x + f.y * wa1.y + f.z * wa1.z + f.w * wa1.w;
+        float dv = f.x * wv.x + f.y * wv.y + f.z * wv.z + f.w * wv.w;
+#pragma unroll
+        for (int mm = 32; mm >= 1; mm >>= 1) {  // butterfly: every lane ends with the same three sums
+            d0 += __shfl_xor(d0, mm, 64);
+            d1 += __shfl_xor(d1, mm, 64);
+            dv += __shfl_xor(dv, mm, 64);
+        }
+        const float mean0 = d0 + ba0, mean1 = d1 + ba1, value = dv + bv;
+        const float2 act = reinterpret_cast<const float2*>(A.actions)[i];
+        const float e0 = act.x - mean0, e1 = act.y - mean1;
+        const float lp = -0.5f * (e0 * e0 + e1 * e1) * A.inv_var + A.lp_const;  // log N(a; mean, var I)
+        const float ret = A.returns[i];
+        const float ratio = __expf(lp - A.old_lp[i]);
+        const float adv = ret - value;
+        const float lo = 1.0f - A.eps_clip, hi = 1.0f + A.eps_clip;
+        const float clipped = fminf(fmaxf(ratio, lo), hi);
+        const float s1 = ratio * adv, s2 = clipped * adv;
+        const bool through = (ratio >= lo && ratio <= hi) || s1 < s2;  // the branch of min() that depends on the policy
+        const float dlp = through ? -adv * ratio * invM : 0.0f;        // d loss / d lp
+        const float gm0 = dlp * e0 * A.inv_var, gm1 = dlp * e1 * A.inv_var, gval = (value - ret) * invM;
+        g0.x += gm0 * f.x; g0.y += gm0 * f.y; g0.z += gm0 * f.z; g0.w += gm0 * f.w;
+        g1.x += gm1 * f.x; g1.y += gm1 * f.y; g1.z += gm1 * f.z; g1.w += gm1 * f.w;
+        gv.x += gval * f.x; gv.y += gval * f.y; gv.z += gval * f.z; gv.w += gval * f.w;
+        gb0 += gm0; gb1 += gm1; gbv += gval;  // (identical in every lane: lane 0's copy is used)
+        lsum += -fminf(s1, s2);
+        vsum += (value - ret) * (value - ret);
+    }
+    // waves -> block (fixed order) -> this block's row of the scratch
+    float* sp = s_part[wave];
+    reinterpret_cast<float4*>(sp)[lane] = g0;
+    reinterpret_cast<float4*>(sp + kPpoFeat)[lane] = g1;
+    if (lane == 0) {
+        sp[2 * kPpoFeat] = gb0;
+        sp[2 * kPpoFeat + 1] = gb1;
+        sp[3 * kPpoFeat + 2] = gbv;
+        sp[kPpoParams] = lsum;
+        sp[kPpoParams + 1] = vsum;
+    }
+    // (W_v starts at 2 * 256 + 2: not 16-byte aligned in this layout - scalar stores)
+    sp[2 * kPpoFeat + 2 + 4 * lane] = gv.x;
+    sp[2 * kPpoFeat + 2 + 4 * lane + 1] = gv.y;
+    sp[2 * kPpoFeat + 2 + 4 * lane + 2] = gv.z;
+    sp[2 * kPpoFeat + 2 + 4 * lane + 3] = gv.w;
+    __syncthreads();
+    float* mine = A.partials + (size_t)blockIdx.x * kPpoPartial;
+    for (int k = tid; k < kPpoPartial; k += kPpoThreads) {
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < kPpoThreads / 64; ++w) a += s_part[w][k];
+        mine[k] = a;
+    }
+    // last block to arrive reduces the rows and takes the optimiser step
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(A.counter, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const float t = A.step[0] + 1.0f;
+    const float bc1 = 1.0f - powf(A.beta1, t), bc2s = sqrtf(1.0f - powf(A.beta2, t));
+    __shared__ float s_loss[2];
+    for (int k = tid; k < kPpoPartial; k += kPpoThreads) {
+        float g = 0.f;
+#pragma unroll 16
+        for (unsigned b = 0; b < gridDim.x; ++b) g += A.partials[(size_t)b * kPpoPartial + k];  // (<= 64 rows, loads in flight together)
+        if (k >= kPpoParams) {
+            s_loss[k - kPpoParams] = g;
+            continue;
+        }
+        float* p;
+        float lr;
+        if (k < 2 * kPpoFeat) { p = A.w_a + k; lr = A.lr_actor; }
+        else if (k < 2 * kPpoFeat + 2) { p = A.b_a + (k - 2 * kPpoFeat); lr = A.lr_actor; }
+        else if (k < 3 * kPpoFeat + 2) { p = A.w_v + (k - 2 * kPpoFeat - 2); lr = A.lr_critic; }
+        else { p = A.b_v; lr = A.lr_critic; }
+        const float mk = A.beta1 * A.m[k] + (1.0f - A.beta1) * g;
+        const float vk = A.beta2 * A.v[k] + (1.0f - A.beta2) * g * g;
+        A.m[k] = mk;
+        A.v[k] = vk;
+        *p -= (lr / bc1) * mk / (sqrtf(vk) / bc2s + A.adam_eps);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float vloss = s_loss[1] * invM;
+        A.losses[0] = s_loss[0] * invM + 0.5f * vloss - A.ent_term;
+        A.losses[1] = vloss;
+        A.step[0] = t;
+        *A.counter = 0u;
+    }
+}

@@ -1,21 +1,23 @@
 """Diagnostic (GPU box): why do GPU and oracle differ at the unexplained pixels of a sweep case?
-   python scripts/dbg/explain.py seed [seed ...]"""
+   python scripts/dbg/explain.py [wide] seed [seed ...]"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from scripts.parity_sweep import case_of
+from scripts.parity_sweep import case_of, case_of_wide
 from tests import parity_utils as PU
 from oracle import p3d_restate as O
 
-for seed in map(int, sys.argv[1:]):
-    c = case_of(seed)
+wide = sys.argv[1] == "wide"
+for seed in map(int, sys.argv[2 if wide else 1:]):
+    c = case_of_wide(seed) if wide else case_of(seed)
     res = PU.run_parity_case(**c)
     print("seed", seed, c, {k: v for k, v in res.items() if k != "unexplained"})
     case = PU.make_case(c["n_env"], seed, c["mesh"], c["az_range"])
-    got = PU.run_engine(case, c["img"], radius=c["radius"])
-    S, K = c["img"], 100
+    S, K = c["img"], c.get("faces_per_pixel", 100)
+    got = PU.run_engine(case, c["img"], radius=c["radius"], faces_per_pixel=K)
+    print("   engine: loss0 %s loss %s reward %s" % (got["loss0"].tolist(), got["loss"].tolist(), got["reward"].tolist()))
     for (i, phase, kind, o, y, x, err) in res["unexplained"][:6]:
-        env = PU.oracle_env(case, i, S)
+        env = PU.oracle_env(case, i, S, "flat", K)
         env.reset(radius=c["radius"], azimuth=float(case["az"][i]))
         if phase == "step":
             env.step(case["actions"][i].clone())
@@ -42,6 +44,9 @@ for seed in map(int, sys.argv[1:]):
         print("    n_cand", int(cand.sum()), "rows", len(order))
         if kind == "alpha" and zc.size > K:
             print("    z[K-3..K+3]:", zc[K - 3:K + 3], "gaps", np.diff(zc[K - 3:K + 3]))
+            fz = pc["f"][cand][np.argsort(pc["z"][cand])]
+            for ff in fz[max(K - 2, 0):K + 2]:
+                print("      face %d around the K boundary: conditioning bound of its depth %.3e" % (int(ff), PU.sliver_depth_bound(fv[int(ff)].detach().numpy())))
         nb = np.abs(pc["dist"] - O.BLUR_RADIUS) / O.BLUR_RADIUS
         idx = np.argsort(nb)[:4]
         print("    closest |dist-blur|/blur:", [(int(pc["f"][j]), float(nb[j]), int(pc["flags"][j])) for j in idx])

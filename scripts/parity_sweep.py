@@ -1,5 +1,6 @@
 """Randomised parity sweep (GPU box): many seeded scenes through the HIP engine and the CPU oracle.
-    python scripts/parity_sweep.py [n_seeds [first_seed]]     -> one line per case + a summary; exit 1 on a violation.
+    python scripts/parity_sweep.py [n_seeds [first_seed [wide]]]     -> one line per case + a summary; exit 1 on a violation.
+"wide" also varies K (100 / 50 / 8 faces per pixel), the image side (64 ... 160) and the camera distance (1.3 ... 6).
 A case is "ok" under EXACTLY the criterion of the parity tests (tests/parity_utils.py: violations): 1e-4 everywhere,
 every pixel beyond it an oracle-verified exact tie, loss / reward / gradient at 1e-4 with the ties weighted out."""
 import os
@@ -18,12 +19,22 @@ def case_of(seed):
     return dict(n_env=2, img=img, seed=seed, mesh=mesh, az_range=az, radius=radius)
 
 
+def case_of_wide(seed):
+    """More of the parameter space per case than case_of: K, image side and camera distance vary independently."""
+    mesh = ("teapot", "synthetic", "mixed", "textured")[seed % 4]
+    img = (64, 96, 128, 160)[(seed // 4) % 4] if mesh != "mixed" else (64, 96)[(seed // 4) % 2]
+    K = (100, 50, 8)[(seed // 16) % 3]
+    radius = (4.0, 2.5, 1.3, 6.0)[(seed // 48) % 4] if mesh != "mixed" else (4.0, 6.0)[(seed // 48) % 2]
+    return dict(n_env=2, img=img, seed=seed, mesh=mesh, az_range=(0.6, 3.0)[seed % 2], radius=radius, faces_per_pixel=K)
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     base = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
     worst, bad, ties, t0 = {}, 0, 0, time.time()
     for seed in range(base, base + n):
-        c = case_of(seed)
+        c = case_of_wide(seed) if wide else case_of(seed)
         res = run_parity_case(**c)
         v = violations(res)
         bad += 1 if v else 0
@@ -31,8 +42,8 @@ if __name__ == "__main__":
         for k, val in res.items():
             if isinstance(val, float):
                 worst[k] = max(worst.get(k, 0.0), val)
-        print("seed %d %-9s %3d az %.1f r %.1f  %s  alpha %.1e obs %.1e loss %.1e reward %.1e grad %.1e ties %d %s" % (
-            seed, c["mesh"], c["img"], c["az_range"], c["radius"], "BAD" if v else "ok ", res["alpha_maxabs"],
+        print("seed %d %-9s %3d K %3d az %.1f r %.1f  %s  alpha %.1e obs %.1e loss %.1e reward %.1e grad %.1e ties %d %s" % (
+            seed, c["mesh"], c["img"], c.get("faces_per_pixel", 100), c["az_range"], c["radius"], "BAD" if v else "ok ", res["alpha_maxabs"],
             res["obs_maxabs"], res["loss_rel"], res["reward_abs"], res["grad_rel"], res["tie_pixels"],
             ("arbiter " + " ".join("gpu %.0f orc32 %.0f eps*M" % (a["e_gpu"] / (2.0 ** -24 * a["mass"]), a["e_orc32"] / (2.0 ** -24 * a["mass"])) for a in res["grad_arbiter"]) + " " if res["grad_arbiter"] else "")
             + "; ".join(v)), flush=True)

@@ -3,8 +3,9 @@ same seeded scenes through the HIP engine and through the CPU oracle (oracle/p3d
 This is checker code: it is the only place (with tests/) where oracle/ and the product meet.
 
 Tolerance: 1e-4 fp32 (BASELINE.json north_star) on EVERY pixel of the observation, the three silhouette alphas and
-the occlusion image, on loss and reward, and relative 1e-4 (L2) on d reward / d action -- with one documented
-exception, checked pixel by pixel instead of masked wholesale:
+the occlusion image, on loss and reward (relative to max(1, |value|) for the occlusion image, 0 ... 3, and the reward,
+which is a loss of ~100 when objectMass = 1), and relative 1e-4 (L2) on d reward / d action -- with documented
+exceptions, checked pixel by pixel instead of masked wholesale:
 
 EXACT TIES.  The oracle and the HIP path reach a pixel with vertex coordinates that differ in the last bits (torch's
 CPU matmul / libm vs the setup kernel's own arithmetic), so a DISCRETE decision can fall either way when it is
@@ -23,6 +24,15 @@ face is a needle (area << perimeter^2).  Barycentrics are edge functions divided
 them by up to 2 delta perimeter / |area| and the interpolated depth by that times the face's depth range; such a pixel
 is accepted only while its depth error stays within TOL + that first-order bound AND its colour is within TOL
 (parity sweep seed 2084: a 0.004-pixel-wide needle over a pixel centre, depth off by 1.9e-4, bound 1.6e-3).
+
+NEAR AND Z-CLIPPED FACES.  The projection divides by the view depth: a view-space coordinate noise TVIEW becomes
+TVIEW (s + |x_ndc|) / z in NDC (s = 1 / tan 30 deg), and the cut vertex of a face that straddles the clip plane
+z = 0.5 moves by (TVIEW / 0.5) (s + 2 |s (X_b - X_a)| / |z_a - z_b|) - unbounded for an edge parallel to the plane.
+With the camera inside an object (radius 2.5 in the wide sweep) such faces move an alpha by up to 6e-4 with nothing
+tied.  A pixel beyond tolerance is then accepted only if ALL of this holds, machine-checked: (1) every face record of
+the engine's setup kernel for that object equals the oracle's (clipped) face within the bound above (vertex by vertex);
+(2) the ORACLE's rasteriser run on the ENGINE's own records reproduces the engine's alpha at that pixel within TOL
+(i.e. the raster stage agrees on identical geometry); (3) a face whose bound exceeds TVERT is a candidate there.
 
 ACTION GRADIENT.  d reward / d action is a sum of ~1e5 signed fp32 per-pixel terms (2 I dI/d alpha_o * d alpha_o/d theta,
 each itself -(A/sigma) * a sum of ~100 signed terms).  When the pixel terms nearly cancel (|g| is 1/30 ... 1/200 of
@@ -54,6 +64,7 @@ TPAIR_REL = 1e-4    # |d1 - d2| <= TPAIR_REL * max(d): the halves of a z-clipped
 TEDGE = 5e-7        # pixel centre within this (NDC units, ~8 ulp of a coordinate) of a face edge: inside test can flip
 TAREA = 2e-9        # |signed area - kEpsilon(1e-8)| <= TAREA + TVERT * perimeter: the face is visible / culled by a hair
 TVERT = 2.5e-7      # vertex-coordinate noise between the two fp32 projections (measured max 2.4e-7 = 1 ulp at |view coord| in [2,4))
+TVIEW = 5e-7        # view-space coordinate noise between the two fp32 camera transforms (1 ulp at |coordinate| in [4, 8))
 TTEXEL = 1e-3       # barycentric * R within this of a texel-cell boundary
 GRAD_NOISE_ULPS = 256.0  # fp32 noise floor of the action gradient, in units of eps * (L1 mass of its pixel terms)
 TEAPOT = os.path.join(ROOT, "data", "teapot.obj")
@@ -138,13 +149,14 @@ def run_engine(case, img, n_env=None, faces_per_pixel=100, radius=4.0, pixel_wei
         eng.pixel_weight = pixel_weight.to(eng.device, torch.float32).contiguous()
     obs0, loss0, fs0 = eng.reset_render(None, radius, case["az"][:n], 0.0)
     alphas0 = eng.alphas.clone()
+    records0 = snapshot_records(eng)
     a = case["actions"][:n].to(eng.device).requires_grad_(True)
     obs, reward, done, fs, loss = eng.step(a)
     reward.sum().backward()
     eng.check_status()
     out = dict(engine=eng, obs0=obs0.cpu(), loss0=loss0.cpu(), fs0=fs0.cpu(), alphas0=alphas0.cpu(), obs=obs.cpu(),
                reward=reward.detach().cpu(), done=done.cpu(), fs=fs.cpu(), loss=loss.cpu(), grad=a.grad.cpu(),
-               campos=eng.camera_position.cpu())
+               campos=eng.camera_position.cpu(), records0=records0, records=snapshot_records(eng))
     out.update(engine_grad_parts(eng))
     if render_too:  # OcclusionEnv.render() at the camera position the step left behind (environment.py:332-347)
         out["render"] = eng.render_hard().cpu()
@@ -185,6 +197,7 @@ class _Faces:
         from oracle import p3d_restate as O
 
         ndc = O.world_to_ndc(verts, R, T).detach()
+        self.fv_unclipped = ndc[faces].contiguous()
         self.fv, self.c2u, self.nb, _, _ = O.clip_faces(ndc[faces], O.Z_CLIP, True)
         self.fv = self.fv.detach().contiguous()
 
@@ -239,6 +252,116 @@ def sliver_depth_bound(fv_face) -> float:
     return 2.0 * TVERT * perim / max(area, 1e-30) * float(v[:, 2].max() - v[:, 2].min())
 
 
+def snapshot_records(eng):
+    """The face records the setup kernel left for the LAST render, per (env, object): NDC vertices (n,3,3), original
+    face ids, flags (occ_constants.h: 1 / 2 = first / second half of a z-clipped pair, 4 = z-clipped piece)."""
+    torch.cuda.synchronize()
+    nrec = eng._ws_tensors["nrec"].cpu().numpy()[: eng.NT * 3]
+    rec_off = eng._rec_tensors["rec_off"].cpu().numpy().view(np.int64)
+    rec = eng._rec_tensors["rec"].view(torch.float32)
+    out = []
+    for eo in range(eng.N * 3):
+        n, base = int(nrec[eo]), int(rec_off[eo])
+        r = rec[base * 32: (base + n) * 32].cpu().numpy().reshape(n, 32).copy()
+        out.append(dict(fv=torch.from_numpy(r[:, :9].reshape(n, 3, 3).copy()), ids=r[:, 9].view(np.int32).copy(),
+                        flags=r[:, 10].view(np.int32).copy()))
+    return out
+
+
+def face_noise_bounds(fv_unclipped) -> np.ndarray:
+    """Per ORIGINAL face: bound on the NDC displacement of any vertex of the face (or of its z-clipped pieces) under
+    view-space coordinate noise TVIEW (module docstring, NEAR AND Z-CLIPPED FACES); never below TVERT."""
+    from oracle import p3d_restate as O
+
+    v = fv_unclipped.double().numpy()  # (F,3,3): x_ndc, y_ndc, z_view
+    s = float(O.proj_scale(torch.float64))
+    x, y, z = v[..., 0], v[..., 1], v[..., 2]
+    front = z >= O.Z_CLIP
+    with np.errstate(divide="ignore", invalid="ignore"):
+        own = np.where(front, TVIEW * (s + np.maximum(np.abs(x), np.abs(y))) / np.maximum(z, O.Z_CLIP), 0.0).max(1)
+        bound = np.maximum(own, TVERT)
+        for a, b in ((0, 1), (1, 2), (2, 0)):
+            cut = front[:, a] != front[:, b]
+            dxy = np.maximum(np.abs(x[:, b] * z[:, b] - x[:, a] * z[:, a]), np.abs(y[:, b] * z[:, b] - y[:, a] * z[:, a]))
+            bc = (TVIEW / O.Z_CLIP) * (s + 2.0 * dxy / np.maximum(np.abs(z[:, a] - z[:, b]), 1e-30))
+            bound = np.where(cut, np.maximum(bound, bc), bound)
+    return bound
+
+
+def upstream_check(faces: _Faces, rec):
+    """(1) of NEAR AND Z-CLIPPED FACES: every engine record against the oracle's face of the same id / half.  Returns
+    (ok, worst |difference| / bound, per-original-face bounds)."""
+    bounds = face_noise_bounds(faces.fv_unclipped)
+    ofv = faces.fv.double().numpy()
+    # oracle pieces of every original face (one; two for a face split by the clip plane; none if all of it is behind)
+    if faces.c2u is None:
+        pieces = {k: [k] for k in range(ofv.shape[0])}
+    else:
+        pieces = {}
+        for c, k in enumerate(faces.c2u.numpy().tolist()):
+            if k >= 0:
+                pieces.setdefault(k, []).append(c)
+    worst = 0.0
+    ev = rec["fv"].double().numpy()
+    for j in range(ev.shape[0]):
+        k = int(rec["ids"][j])
+        cs = pieces.get(k, [])
+        if len(cs) == 2 and rec["flags"][j] & 3:  # a half that knows its partner: first / second as the oracle lists them
+            cs = [cs[1] if rec["flags"][j] & 2 else cs[0]]
+        if not cs:
+            return False, float("inf"), bounds
+        best = float("inf")
+        for c in cs:  # (a half whose partner is invisible carries no pair flag: whichever piece it is)
+            # vertex by vertex, whatever the order the two sides list them in
+            dm = np.abs(ev[j, :, None, :] - ofv[c, None, :, :])  # (3 engine, 3 oracle, xyz)
+            m = dm[..., :2].max(-1).argmin(1)
+            d = dm[np.arange(3), m, :2].max()
+            dz = dm[np.arange(3), m, 2].max()
+            best = min(best, max(d / bounds[k], dz / (2.0 * TVIEW)))
+        worst = max(worst, best)
+    return worst <= 1.0, worst, bounds
+
+
+def alpha_of_records(rec, S, K):
+    """(2): the ORACLE's naive rasteriser + sigmoid blend on the engine's own records (identical geometry)."""
+    from oracle import p3d_restate as O
+
+    fv = rec["fv"].float().contiguous()
+    if fv.shape[0] == 0:
+        return torch.zeros(S, S)
+    fl = rec["flags"]
+    nb = np.full(fv.shape[0], -1, dtype=np.int64)
+    idx = np.arange(fv.shape[0])
+    nb[(fl & 1) != 0] = idx[(fl & 1) != 0] + 1
+    nb[(fl & 2) != 0] = idx[(fl & 2) != 0] - 1
+    p2f, _, _, dists = O._Rasterize.apply(fv, torch.from_numpy(nb), S, float(O.BLUR_RADIUS), K, True, True, True)
+    return O.sigmoid_alpha_blend(dists, p2f)[..., 3]
+
+
+class _Upstream:
+    """Second chance for an unexplained alpha pixel (module docstring, NEAR AND Z-CLIPPED FACES); caches per object."""
+
+    def __init__(self, records_env, S, K):
+        self.rec, self.S, self.K, self.cache = records_env, S, K, {}
+
+    def explain(self, faces: _Faces, o, yi, xi, got_alpha):
+        from oracle import p3d_restate as O
+
+        if self.rec is None:
+            return []
+        if o not in self.cache:
+            ok, worst, bounds = upstream_check(faces, self.rec[o])
+            self.cache[o] = (ok, worst, bounds, alpha_of_records(self.rec[o], self.S, self.K) if ok else None)
+        ok, worst, bounds, al = self.cache[o]
+        if not ok or abs(float(al[yi, xi]) - float(got_alpha)) > TOL:
+            return []
+        c = O.pixel_candidates(faces.fv, self.S, yi, xi, O.BLUR_RADIUS, band=10 * TB_REL, area_band=TAREA, vert_band=TVERT)
+        orig = c["f"] if faces.c2u is None else faces.c2u.numpy()[c["f"]]
+        if not (bounds[orig] > TVERT).any():
+            return []
+        return ["near / z-clipped face: vertex noise upstream, the raster of the engine's own records agrees"]
+
+
 def explain_hard(faces: _Faces, S, yi, xi, err_rgb=None, err_depth=None, hair_faces=None):
     """Near-ties of the hard (K = 1) rasterisation at one pixel.  With the pixel's colour / depth errors given, the
     ill-conditioned depth of a needle face is accepted within its bound as well."""
@@ -289,13 +412,14 @@ def explain_texel(env, S, yi, xi):
 HAIR = "face visible / culled by a hair (area ~ kEpsilon)"
 
 
-def _classify(env, got_alphas, or_alphas, got_obs, or_obs, S, K, textured, decisions=None):
+def _classify(env, got_alphas, or_alphas, got_obs, or_obs, S, K, textured, decisions=None, records=None):
     """Pixels beyond tolerance -> (tie mask (S,S) bool, list of unexplained (kind, obj, y, x, err)).  ``decisions`` (a
     set) collects what max_tie_pixels bounds: one entry per tie pixel, except that the pixels whose ONLY reason is the
     visibility of a needle face share one entry per such face (its whole blur footprint flips with it)."""
     ties = torch.zeros(S, S, dtype=torch.bool)
     unexplained = []
     decisions = set() if decisions is None else decisions
+    upstream = _Upstream(records, S, K)
     R, T = env.R[0], env.T[0]
     dal = (or_alphas - got_alphas).abs()
     faces_cache = {}
@@ -304,6 +428,8 @@ def _classify(env, got_alphas, or_alphas, got_obs, or_obs, S, K, textured, decis
             faces_cache[o] = _Faces(env.objs[o][0], env.objs[o][1], R, T)
         hf = set()
         why = explain_soft(faces_cache[o], S, y, x, K, hair_faces=hf)
+        if not why:
+            why = upstream.explain(faces_cache[o], o, y, x, got_alphas[o, y, x])
         if why:
             ties[y, x] = True
             decisions.update(("face", o, f) for f in hf) if HAIR in why else decisions.add(("pixel", y, x))
@@ -349,11 +475,13 @@ def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_
         obs0 = env.reset(radius=radius, azimuth=float(case["az"][i]))
         al0 = torch.stack([im[0, ..., 3] for im in env.alphas]).detach()
         img0 = env.image.detach()
-        t0, u0 = _classify(env, got["alphas0"][i], al0, got["obs0"][i], obs0[0].detach(), S, K, textured, dec)
+        t0, u0 = _classify(env, got["alphas0"][i], al0, got["obs0"][i], obs0[0].detach(), S, K, textured, dec,
+                         records=got["records0"][3 * i: 3 * i + 3])
         a = case["actions"][i].clone().requires_grad_(True)
         obs, reward, done, info = env.step(a)
         al = torch.stack([im[0, ..., 3] for im in env.alphas]).detach()
-        t1, u1 = _classify(env, got["alphas"][i], al, got["obs"][i], obs[0].detach(), S, K, textured, dec)
+        t1, u1 = _classify(env, got["alphas"][i], al, got["obs"][i], obs[0].detach(), S, K, textured, dec,
+                         records=got["records"][3 * i: 3 * i + 3])
         rnd = None
         if check_render:
             rimg, rdepth = env.render()
@@ -379,9 +507,11 @@ def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_
         res["obs0_maxabs"] = max(res["obs0_maxabs"], float(((o["obs0"] - got["obs0"][i]).abs() * keep0).max()))
         res["alpha_maxabs"] = max(res["alpha_maxabs"], float(((o["al"] - got["alphas"][i]).abs() * keep1).max()))
         res["alpha0_maxabs"] = max(res["alpha0_maxabs"], float(((o["al0"] - got["alphas0"][i]).abs() * keep0).max()))
+        # the occlusion image is a sum of three products of alphas, 0 ... 3: 1e-4 of its magnitude where that exceeds 1
         fs_or = env.image[0].detach()
-        res["fs_maxabs"] = max(res["fs_maxabs"], float(((fs_or - got["fs"][i]).abs() * keep1[..., None]).max()),
-                               float(((o["img0"][0] - got["fs0"][i]).abs() * keep0[..., None]).max()))
+        res["fs_maxabs"] = max(res["fs_maxabs"],
+                               float(((fs_or - got["fs"][i]).abs() / fs_or.abs().clamp(min=1.0) * keep1[..., None]).max()),
+                               float(((o["img0"][0] - got["fs0"][i]).abs() / o["img0"][0].abs().clamp(min=1.0) * keep0[..., None]).max()))
         if o["render"] is not None:
             res["render_maxabs"] = max(res["render_maxabs"], float(((o["render"] - got["render"][i]).abs() * keep1).max()))
         # loss / reward / gradient with the tie pixels weighted out (environment.py:381-392 restated on the images)
@@ -396,7 +526,8 @@ def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_
         lo = float(loss)
         res["loss_rel"] = max(res["loss_rel"], abs(lo - float(got_w["loss"][i])) / max(abs(lo), 1.0))
         res["loss0_rel"] = max(res["loss0_rel"], abs(float(loss0) - float(got_w["loss0"][i])) / max(abs(float(loss0)), 1.0))
-        res["reward_abs"] = max(res["reward_abs"], abs(float(reward) - float(got_w["reward"][i])))
+        # (1e-4 of the reward's magnitude where that exceeds 1: with objectMass = 1 the reward IS a loss of ~100)
+        res["reward_abs"] = max(res["reward_abs"], abs(float(reward) - float(got_w["reward"][i])) / max(abs(float(reward)), 1.0))
         # fp32 cancellation noise or a real error?  beyond 1e-4 the f64 oracle arbitrates (module docstring)
         gc = grad_check(got_w["grad"][i], g, lambda: _oracle_grad64(case, i, img, radius, w, faces_per_pixel),
                         lambda: gradient_mass(got_w, i, w))

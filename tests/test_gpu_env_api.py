@@ -642,6 +642,53 @@ def test_env_on_a_shapenetcore_directory(tmp_path):
     assert o2.shape == (4, 4, 64, 64) and torch.isfinite(r2).all()
 
 
+def test_fused_ppo_update_equals_the_torch_one():
+    """occ_ppo_update (csrc/occ_ppo.hpp: forward, clipped-surrogate loss, backward and Adam of one epoch in ONE launch)
+    against the torch implementation of the same epochs (autograd + torch.optim.Adam, PPO.py:196-217), over two updates,
+    the second with a decayed action std (PPO.py:136-149).  Five epochs per update: every parameter to 1e-6 (measured
+    6e-8).  Eighty (trainRL.py): the critic to 1e-5; the ACTOR's trajectory amplifies rounding differences through the
+    clip boundary (a sample crossing it switches its whole gradient on or off: 4e-9 after one epoch, 3e-6 after 20,
+    5e-4 after 80, scripts/dbg/ppo_fused_diff.py) - held to 5 % of the distance the update moved it."""
+    from occlusionenv_amd import ppo, rollout
+
+    g = torch.Generator(device="cuda").manual_seed(7)
+    recs = []
+    for _u in range(2):
+        r = torch.randn(20, 128, rollout.RECORD_FLOATS, device="cuda", generator=g)
+        r[..., :256] = r[..., :256].abs() * 0.5                 # pooled features of an image: non-negative
+        r[..., 256:258] *= 0.6                                  # actions
+        r[..., 258] = -1.5 + 0.3 * r[..., 258]                  # old log-probabilities
+        r[..., 260] = (torch.rand(20, 128, device="cuda", generator=g) < 0.05).float()
+        recs.append(r)
+    init = [p.detach().clone() for p in ppo.BatchedPPO(device="cuda", seed=3, fused=False).policy.parameters()]
+    for K in (5, 80):
+        out = []
+        for fused in (True, False):
+            agent = ppo.BatchedPPO(device="cuda", seed=3, K_epochs=K, graph_epochs=False, fused=fused)
+            assert agent.fused == fused
+            stats = []
+            for u, r in enumerate(recs):
+                if u == 1:
+                    agent.decay_action_std(0.05, 0.1)
+                for t in range(r.shape[0]):
+                    agent.store(r[t])
+                stats.append(agent.update())
+            out.append(([p.detach().clone() for p in agent.policy.parameters()], stats,
+                        [p.detach().clone() for p in agent.policy_old.parameters()]))
+        names = [n for n, _ in ppo.BatchedPPO(device="cuda", seed=3, fused=False).policy.named_parameters()]
+        for n, a, b, p0 in zip(names, out[0][0], out[1][0], init):
+            moved, diff = float((b - p0).abs().max()), float((a - b).abs().max())
+            assert moved > 1e-4                                    # the Adam steps did move the heads
+            bound = 1e-6 if K == 5 else (1e-5 if n.startswith("value_head") else 5e-2 * moved)
+            assert diff < bound, (K, n, diff, moved)
+        for a, b in zip(out[0][2], out[0][0]):
+            assert torch.equal(a, b)                            # policy_old follows the updated policy
+        for sa, sb in zip(out[0][1], out[1][1]):
+            assert sa["samples"] == sb["samples"] == 20 * 128
+            for k in ("loss_first", "loss_last", "value_loss_first", "value_loss_last"):
+                assert abs(sa[k] - sb[k]) < (1e-5 if K == 5 else 1e-3) * max(1.0, abs(sb[k])), (K, k, sa[k], sb[k])
+
+
 def test_graphed_ppo_epochs_equal_the_eager_ones():
     """BatchedPPO.update on the GPU replays ONE captured HIP graph for epochs 4..K: the heads it leaves behind must be
     those of the same epochs launched one by one, over two updates (the second reuses the graph with new data)."""
@@ -656,7 +703,7 @@ def test_graphed_ppo_epochs_equal_the_eager_ones():
         recs.append(r)
     heads = []
     for graph in (True, False):
-        agent = ppo.BatchedPPO(device="cuda", seed=3, K_epochs=20, graph_epochs=graph)
+        agent = ppo.BatchedPPO(device="cuda", seed=3, K_epochs=20, graph_epochs=graph, fused=False)
         stats = []
         for r in recs:
             for t in range(r.shape[0]):

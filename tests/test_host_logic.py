@@ -333,7 +333,7 @@ def test_tie_classifier_bands_are_frozen():
     tightened, never loosened, without this test being changed on purpose."""
     from tests import parity_utils as pu
 
-    frozen = dict(TOL=1e-4, TZ_REL=1e-6, TB_REL=1e-4, TPAIR_REL=1e-4, TEDGE=5e-7, TAREA=2e-9, TVERT=2.5e-7, TTEXEL=1e-3,
+    frozen = dict(TOL=1e-4, TZ_REL=1e-6, TB_REL=1e-4, TPAIR_REL=1e-4, TEDGE=5e-7, TAREA=2e-9, TVERT=2.5e-7, TVIEW=5e-7, TTEXEL=1e-3,
                   GRAD_NOISE_ULPS=256.0)
     for name, bound in frozen.items():
         assert 0 < getattr(pu, name) <= bound, (name, getattr(pu, name), bound)
@@ -369,6 +369,57 @@ def test_hair_band_scales_with_the_perimeter_and_needle_depth_bound():
     assert 5e-4 < b < 5e-3
     fat = np.array([[0.0, 0.0, 1.5], [0.05, 0.0, 1.52], [0.0, 0.04, 1.48]])
     assert pu.sliver_depth_bound(fat) < 0.05 * pu.TOL
+
+
+def test_vertex_noise_bounds_and_record_matching():
+    """The upstream rule of the classifier (parity_utils: NEAR AND Z-CLIPPED FACES) on the oracle's own geometry: a far
+    face keeps the flat TVERT, a near one grows with 1 / z, a face cut by the clip plane along an edge that runs nearly
+    parallel to it grows with 1 / |z_a - z_b|; records made from the oracle's clipped faces match within the bound with
+    noise below it and fail above it - also for a lone half of a split face that carries no pair flag."""
+    from oracle import p3d_restate as O
+    from tests import parity_utils as pu
+
+    s = float(O.proj_scale())
+    def ndc(view):  # (3,3) view-space -> (x_ndc, y_ndc, z_view)
+        v = torch.tensor(view, dtype=torch.float32)
+        return torch.stack([v[:, 0] * s / v[:, 2], v[:, 1] * s / v[:, 2], v[:, 2]], 1)
+
+    far = ndc([[0.0, 0.0, 4.0], [0.3, 0.0, 4.1], [0.0, 0.3, 4.0]])
+    near = ndc([[0.0, 0.0, 0.6], [0.3, 0.0, 0.7], [0.0, 0.3, 0.6]])
+    cut1 = ndc([[0.0, 0.0, 0.45], [0.4, 0.0, 0.9], [0.0, 0.4, 0.9]])       # one vertex behind: split in two
+    flat = ndc([[0.0, 0.0, 0.4995], [0.5, 0.0, 0.5005], [0.0, 0.4, 0.9]])   # an edge almost inside the clip plane
+    fv = torch.stack([far, near, cut1, flat])
+    b = pu.face_noise_bounds(fv)
+    assert b[0] == pu.TVERT
+    assert pu.TVERT < b[1] < 4 * pu.TVERT * 4.0 / 0.6
+    assert b[2] > b[1] and b[3] > 50 * b[2]
+
+    class F:
+        pass
+
+    faces = F()
+    faces.fv_unclipped = fv
+    faces.fv, faces.c2u, faces.nb, _, _ = O.clip_faces(fv, O.Z_CLIP, True)
+    c2u = faces.c2u.numpy()
+    assert c2u.tolist().count(2) == 2 and c2u.tolist().count(3) == 2   # both straddling faces: one vertex behind -> two pieces
+    flags = np.zeros(len(c2u), dtype=np.int32)
+    for k in (2, 3):
+        i0 = int(np.nonzero(c2u == k)[0][0])
+        flags[i0], flags[i0 + 1] = 1 | 4, 2 | 4
+    rec = dict(fv=faces.fv.clone(), ids=c2u.astype(np.int32), flags=flags)
+    ok, worst, _ = pu.upstream_check(faces, rec)
+    assert ok and worst == 0.0
+    noisy = dict(rec, fv=faces.fv.clone())
+    noisy["fv"][0, 0, 0] += 0.5 * pu.TVERT
+    assert pu.upstream_check(faces, noisy)[0]
+    noisy["fv"][0, 0, 0] += 2.0 * pu.TVERT
+    assert not pu.upstream_check(faces, noisy)[0]
+    # the second half of face 2 alone, without pair flags (its partner invisible): matched to whichever piece it is
+    i1 = int(np.nonzero(c2u == 2)[0][1])
+    lone = dict(fv=faces.fv[i1:i1 + 1].clone(), ids=np.array([2], dtype=np.int32), flags=np.array([4], dtype=np.int32))
+    assert pu.upstream_check(faces, lone)[0]
+    lone["ids"][0] = 0   # ... but not to another face
+    assert not pu.upstream_check(faces, lone)[0]
 
 
 def test_pool_keys_survive_dataset_address_reuse():
