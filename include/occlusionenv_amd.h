@@ -279,6 +279,13 @@ int occ_ppo_update(const float* feats, const float* actions, const float* old_lo
                    uint32_t* counter, void* stream);
 
 /*
+ * The rollout record's 256 features (PPO.py:155-158 stores the frozen encoder's pooled feature of the acting state; the
+ * network itself is outside this path): 4 channels x 8 x 8 average pooling of the observation, obs (n,4,img,img) ->
+ * feats (n,256) in the order of adaptive_avg_pool2d(obs, 8).reshape(n, 256).  img: a multiple of 8.
+ */
+int occ_pool8(const float* obs, int64_t n, int img, float* feats, void* stream);
+
+/*
  * Host hand-off of SimpleVecEnv.step_wait (SubProcVecEnv.py:209-218): one int32 buffer
  *   flags[0..n_env) = done, flags[n_env..n_env+n_reserve) = reserve scene passes reset()'s acceptance test
  *   (loss > 0.1, environment.py:327), flags[n_env+n_reserve] = some status word is non-zero

@@ -153,6 +153,7 @@ SYMBOLS = {
                                               C.c_void_p]),
     "occ_ppo_update": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 7 + [C.POINTER(OccPpoState), C.c_int, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "occ_pool8": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "occ_step_flags": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "occ_reset_commit": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 13 + [C.c_int, C.c_void_p]),
     "occ_auto_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -430,6 +430,16 @@ extern "C" int occ_ppo_update(const float* feats, const float* actions, const fl
     return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
 }
 
+extern "C" int occ_pool8(const float* obs, int64_t n, int img, float* feats, void* stream) {
+    if (!obs || !feats || n <= 0 || img < 8 || img % 8) return OCC_ERR_ARG;
+    const dim3 grid((unsigned)(n * 4 * 8));
+    if ((img / 8) % 4 == 0)
+        hipLaunchKernelGGL(occ_pool8_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, obs, feats, img);
+    else
+        hipLaunchKernelGGL(occ_pool8_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, obs, feats, img);
+    return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
+}
+
 extern "C" int occ_step_flags(const uint8_t* done, const float* loss_all, const int32_t* status, int n_env, int n_reserve,
                               int32_t* flags, void* stream) {
     if (!done || !status || !flags || n_env <= 0 || n_reserve < 0 || (n_reserve > 0 && !loss_all)) return OCC_ERR_ARG;

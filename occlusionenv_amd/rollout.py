@@ -28,6 +28,18 @@ def env_shard(n_total: int, rank: int, world: int):
 def pooled_features(obs: torch.Tensor) -> torch.Tensor:
     """Stand-in for the frozen encoder's 256-d pooled feature (PPO.py:155-157 takes FullNetwork features;
     the network itself is out of scope): 4 channels x 8x8 adaptive average pool."""
+    if obs.is_cuda and obs.dtype == torch.float32 and obs.dim() == 4 and obs.shape[1] == 4 and obs.shape[2] == obs.shape[3] \
+            and obs.shape[2] % 8 == 0:
+        # one pass at memory speed in the library (csrc/occ_ppo.hpp: occ_pool8_kernel); no fallback if it is missing
+        import ctypes as C
+
+        from . import _native as nat
+
+        o = obs.detach().contiguous()
+        feats = torch.empty(o.shape[0], 256, dtype=torch.float32, device=o.device)
+        nat.check(nat.load().occ_pool8(C.c_void_p(o.data_ptr()), int(o.shape[0]), int(o.shape[2]), C.c_void_p(feats.data_ptr()),
+                                       C.c_void_p(torch.cuda.current_stream(o.device).cuda_stream)), "occ_pool8")
+        return feats
     return F.adaptive_avg_pool2d(obs, 8).reshape(obs.shape[0], 256)
 
 

@@ -642,6 +642,25 @@ def test_env_on_a_shapenetcore_directory(tmp_path):
     assert o2.shape == (4, 4, 64, 64) and torch.isfinite(r2).all()
 
 
+@pytest.mark.parametrize("S", [24, 64, 72, 128, 256])
+def test_pool8_equals_adaptive_avg_pool(S):
+    """rollout.pooled_features on the GPU is the library's one-pass kernel (occ_pool8): the 4 x 8 x 8 cell means in the
+    order of F.adaptive_avg_pool2d(obs, 8).reshape(n, 256); cells of 3, 8, 9, 16 and 32 pixels (16-byte and scalar loads)."""
+    import torch.nn.functional as F
+
+    from occlusionenv_amd import rollout
+
+    g = torch.Generator(device="cuda").manual_seed(S)
+    obs = torch.rand(5, 4, S, S, device="cuda", generator=g) * 3.0 - 1.0
+    want = F.adaptive_avg_pool2d(obs.double(), 8).reshape(5, 256)
+    got = rollout.pooled_features(obs)
+    assert got.shape == (5, 256) and got.dtype == torch.float32
+    assert float((got.double() - want).abs().max()) < 1e-6
+    # a non-contiguous view (channels-last memory) goes through the same kernel
+    got2 = rollout.pooled_features(obs.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2))
+    assert torch.equal(got2, got)
+
+
 def test_fused_ppo_update_equals_the_torch_one():
     """occ_ppo_update (csrc/occ_ppo.hpp: forward, clipped-surrogate loss, backward and Adam of one epoch in ONE launch)
     against the torch implementation of the same epochs (autograd + torch.optim.Adam, PPO.py:196-217), over two updates,
