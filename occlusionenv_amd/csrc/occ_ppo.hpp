@@ -158,29 +158,32 @@ __global__ __launch_bounds__(kPpoThreads) void occ_ppo_epoch_kernel(PpoArgs A) {
 // ------------------------------------------------------------------------------------------
 template <bool VEC4>
 __global__ __launch_bounds__(256) void occ_pool8_kernel(const float* __restrict__ obs, float* __restrict__ feats, int S) {
-    __shared__ float s_col[2048];  // column sums of the band (S <= 2048); added up per cell in column order: reproducible
-    const int tid = threadIdx.x;
+    // column sums of the band, one row of the array per wave (the waves share the band's rows: wave w takes rows w, w + 4, ...);
+    // added up per cell in (wave, column) order: reproducible.  S <= 2048.
+    __shared__ float s_col[4][2048];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int oy = blockIdx.x & 7, nc = blockIdx.x >> 3;  // nc = env * 4 + channel
     const int cell = S >> 3;
     const float* band = obs + ((size_t)nc * S + (size_t)oy * cell) * S;
     const int ncol = VEC4 ? (S >> 2) : S;  // VEC4: a float4 column j = pixels 4j .. 4j+3, all of one cell
-    for (int j = tid; j < ncol; j += 256) {
+    for (int j = lane; j < ncol; j += 64) {
         float a = 0.f;
         if (VEC4) {
-            for (int r = 0; r < cell; ++r) {
+            for (int r = wave; r < cell; r += 4) {
                 const float4 v = reinterpret_cast<const float4*>(band + (size_t)r * S)[j];
                 a += (v.x + v.y) + (v.z + v.w);
             }
         } else {
-            for (int r = 0; r < cell; ++r) a += band[(size_t)r * S + j];
+            for (int r = wave; r < cell; r += 4) a += band[(size_t)r * S + j];
         }
-        s_col[j] = a;
+        s_col[wave][j] = a;
     }
     __syncthreads();
     if (tid < 8) {
         const int per = ncol >> 3;  // columns per cell
         float a = 0.f;
-        for (int j = 0; j < per; ++j) a += s_col[tid * per + j];
+        for (int w = 0; w < 4; ++w)
+            for (int j = 0; j < per; ++j) a += s_col[w][tid * per + j];
         feats[(size_t)nc * 64 + oy * 8 + tid] = a / (float)(cell * cell);
     }
 }

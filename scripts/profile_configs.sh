@@ -18,6 +18,7 @@ run config5size_2048x256 --workload shapenet5k --envs 2048 --img 256 --steps 6 -
 run mixed1024 --workload mixed --envs 1024 --img 128 --steps 20 --warmup 3
 # BASELINE config 5 at its per-rank size: PPO rollout (T = 50) + heads-only update, 256 envs, 256x256
 run config5_rank --workload ppo_rollout --steps 100 --warmup 5
+timeout -k 10 400 python bench.py --no-cpu-baseline --workload ppo_rollout --steps 200 --warmup 10 > "$OUT/config5_rank_unprofiled.json" 2> "$OUT/config5_rank_unprofiled.err"
 # N>1 rehearsal from a COLD shell: bench.py starts torch.distributed.run itself (two gloo ranks sharing the single GPU:
 # sharding, the side-stream record exchange, the gather)
 timeout -k 10 400 python bench.py --gpus 2 --dist-backend gloo --envs 512 --steps 50 --warmup 5 > "$OUT/n2_gloo.log" 2>&1

@@ -17,6 +17,12 @@ for logf in sorted(glob.glob(os.path.join(out, "*.log"))):
         continue
     f = sorted(glob.glob(os.path.join(out, tag, "*", "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)  # newest run
     rows = list(csv.DictReader(open(f[0])))[:8] if f else []
-    json.dump({"config": tag, "bench": bench, "kernels": [{k: r[k] for k in ("Name", "Calls", "AverageNs", "Percentage")} for r in rows]},
-              open(os.path.join(root, "profiles", f"{rnd}_{tag}.json"), "w"), indent=1)
+    rec = {"config": tag, "bench": bench, "kernels": [{k: r[k] for k in ("Name", "Calls", "AverageNs", "Percentage")} for r in rows]}
+    unprof = os.path.join(out, tag + "_unprofiled.json")  # the same workload without the profiler (it taxes small launches)
+    if os.path.exists(unprof):
+        ul = [l for l in open(unprof) if l.startswith("{")]
+        if ul:
+            rec["bench_unprofiled"] = json.loads(ul[-1])
+            rec["note"] = "bench = the run under rocprofv3 --kernel-trace (slower: the profiler taxes its small launches); bench_unprofiled = the same command without the profiler"
+    json.dump(rec, open(os.path.join(root, "profiles", f"{rnd}_{tag}.json"), "w"), indent=1)
     print(tag, "%.0f steps/s, %.2f ms/step" % (bench["value"], bench["ms_per_step"]))
