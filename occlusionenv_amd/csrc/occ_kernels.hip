@@ -470,7 +470,7 @@ extern "C" int occ_auto_reset(const uint8_t* done, const float* loss_all, const 
                               const float* full_state_all, const OccReserveStore* store, float* term_obs, int img,
                               int32_t* pairs, int32_t* report, void* stream) {
     if (!done || !loss_all || !status || n_env <= 0 || n_reserve <= 0 || n_reserve > 512 || !rs_state || !rs_tries || !st ||
-        !obs_all || !full_state_all || !store || !term_obs || img <= 0 || !pairs || !report)
+        !obs_all || !full_state_all || !store || !term_obs || img < OCC_TILE || img % OCC_TILE || !pairs || !report)
         return OCC_ERR_ARG;
     if (!st->el || !st->az || !st->radius || !st->campos || !st->cam || !st->alphas || !st->full_reward || !st->object_mass ||
         !st->scene_mesh || !st->scene_offset || !store->obs || !store->full_state || !store->loss || !store->skip)
@@ -481,7 +481,7 @@ extern "C" int occ_auto_reset(const uint8_t* done, const float* loss_all, const 
     PairArgs pa{done, loss_all, status, n_env, n_reserve, rs_state, rs_tries, pairs, report, store->skip};
     hipLaunchKernelGGL(occ_pair_kernel, dim3(1), dim3(1024), 0, s, pa);
     AutoCommitArgs ca{pairs, *st, obs_all, term_obs, store->obs, store->loss, img, n_env};
-    hipLaunchKernelGGL(occ_auto_commit_kernel, dim3(n_reserve, 1 + kCommitObsBlocks + kCommitAlphaBlocks), dim3(256), 0, s, ca);
+    hipLaunchKernelGGL(occ_auto_commit_kernel, dim3(n_reserve, 1 + commit_obs_blocks(img) + commit_alpha_blocks(img)), dim3(256), 0, s, ca);
     return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
 }
 

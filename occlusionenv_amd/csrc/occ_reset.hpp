@@ -123,13 +123,18 @@ struct AutoCommitArgs {
     float* obs_all; float* term_obs; const float* res_obs; const float* res_loss;
     int img, n_env;
 };
-constexpr int kCommitObsBlocks = 8, kCommitAlphaBlocks = 6;
+// grid.y = 1 (state) + obs_blocks + alpha_blocks: the copies are sized by the image - a block moves ~4 x 256 float4 per
+// plane it touches (with the 8 + 6 blocks that were enough at 128 x 128 the commit of ONE env took 40 us at 256 x 256,
+// 128 serial scalar iterations per thread in the alpha part)
+__host__ __device__ inline int commit_obs_blocks(int img) { return max(1, (img * img) / 1024); }
+__host__ __device__ inline int commit_alpha_blocks(int img) { return max(1, (3 * img * img) / 4096); }
 __global__ __launch_bounds__(256) void occ_auto_commit_kernel(AutoCommitArgs a) {
     const int k = blockIdx.x;
     if (k >= a.pairs[0]) return;
     const int dst = a.pairs[2 + 2 * k], src = a.pairs[3 + 2 * k];
     const int tid = threadIdx.x, y = blockIdx.y;
     const size_t S2 = (size_t)a.img * a.img;
+    const int obs_blocks = commit_obs_blocks(a.img), alpha_blocks = commit_alpha_blocks(a.img);
     if (y == 0) {
         if (tid == 0) {
             a.st.el[dst] = a.st.el[src];
@@ -145,20 +150,20 @@ __global__ __launch_bounds__(256) void occ_auto_commit_kernel(AutoCommitArgs a) 
         }
         if (tid < 9) a.st.scene_offset[dst * 9 + tid] = a.st.scene_offset[src * 9 + tid];
         if (tid < OCC_CAM_STRIDE) a.st.cam[(size_t)dst * OCC_CAM_STRIDE + tid] = a.st.cam[(size_t)src * OCC_CAM_STRIDE + tid];
-    } else if (y <= kCommitObsBlocks) {
+    } else if (y <= obs_blocks) {
         // final observation -> term_obs[slot], stored reset observation -> obs[env] (same element range, same thread)
         const float4* s4 = reinterpret_cast<const float4*>(a.res_obs + (size_t)(src - a.n_env) * 4 * S2);
         float4* d4 = reinterpret_cast<float4*>(a.obs_all + (size_t)dst * 4 * S2);
         float4* t4 = reinterpret_cast<float4*>(a.term_obs + (size_t)(src - a.n_env) * 4 * S2);
-        for (size_t i = (size_t)(y - 1) * 256 + tid; i < S2; i += (size_t)kCommitObsBlocks * 256) {
+        for (size_t i = (size_t)(y - 1) * 256 + tid; i < S2; i += (size_t)obs_blocks * 256) {
             t4[i] = d4[i];
             d4[i] = s4[i];
         }
     } else {
-        const float* s1 = a.st.alphas + (size_t)src * 3 * S2;
-        float* d1 = a.st.alphas + (size_t)dst * 3 * S2;
-        for (size_t i = (size_t)(y - 1 - kCommitObsBlocks) * 256 + tid; i < 3 * S2; i += (size_t)kCommitAlphaBlocks * 256)
-            d1[i] = s1[i];
+        // (img is a multiple of 8: the three alpha planes are a whole number of float4)
+        const float4* s4 = reinterpret_cast<const float4*>(a.st.alphas + (size_t)src * 3 * S2);
+        float4* d4 = reinterpret_cast<float4*>(a.st.alphas + (size_t)dst * 3 * S2);
+        for (size_t i = (size_t)(y - 1 - obs_blocks) * 256 + tid; i < 3 * S2 / 4; i += (size_t)alpha_blocks * 256) d4[i] = s4[i];
     }
 }
 

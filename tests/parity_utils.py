@@ -202,10 +202,15 @@ class _Faces:
         self.fv = self.fv.detach().contiguous()
 
 
-def explain_soft(faces: _Faces, S, yi, xi, K, hair_faces=None):
+PAIR = "clipped-pair distance tie"
+
+
+def explain_soft(faces: _Faces, S, yi, xi, K, hair_faces=None, pair_faces=None):
     """Near-ties of the soft rasterisation at one pixel; returns a list of reasons (empty = decision is robust).
     ``hair_faces`` (a set) collects the faces whose visibility is the near-tie: ONE decision per face, however many
-    pixels of its blur footprint it moves."""
+    pixels of its blur footprint it moves.  ``pair_faces`` likewise the z-clipped pairs whose two halves are equally far
+    from the pixel: ONE geometric coincidence per pair (the band of pixels nearest to the edge or vertex the halves
+    share), each pixel of which is then decided by rounding."""
     from oracle import p3d_restate as O
 
     c = O.pixel_candidates(faces.fv, S, yi, xi, O.BLUR_RADIUS, band=10 * TB_REL, area_band=TAREA, vert_band=TVERT)
@@ -236,7 +241,9 @@ def explain_soft(faces: _Faces, S, yi, xi, K, hair_faces=None):
             if p > f and p in fl:
                 d1, d2 = float(c["dist"][j]), float(c["dist"][fl[p]])
                 if abs(d1 - d2) <= TPAIR_REL * max(d1, d2, 1e-12):
-                    why.append("clipped-pair distance tie")
+                    why.append(PAIR)
+                    if pair_faces is not None:
+                        pair_faces.add(f)
                     break
     if ((c["flags"] & 4) != 0).any() or (np.abs(c["z"]) <= 1e-6).any():
         why.append("pz ~ 0")
@@ -410,12 +417,14 @@ def explain_texel(env, S, yi, xi):
 
 
 HAIR = "face visible / culled by a hair (area ~ kEpsilon)"
+REASON_LOG = None  # diagnostics (scripts/dbg): set to a list to collect (kind, obj, y, x, reasons) of every explained pixel
 
 
 def _classify(env, got_alphas, or_alphas, got_obs, or_obs, S, K, textured, decisions=None, records=None):
     """Pixels beyond tolerance -> (tie mask (S,S) bool, list of unexplained (kind, obj, y, x, err)).  ``decisions`` (a
-    set) collects what max_tie_pixels bounds: one entry per tie pixel, except that the pixels whose ONLY reason is the
-    visibility of a needle face share one entry per such face (its whole blur footprint flips with it)."""
+    set) collects what max_tie_pixels bounds: one entry per tie pixel, except that the pixels whose reason is the
+    visibility of a needle face share one entry per such face (its whole blur footprint flips with it), and the pixels
+    whose only reason is the equal distance of the two halves of a z-clipped pair one entry per pair."""
     ties = torch.zeros(S, S, dtype=torch.bool)
     unexplained = []
     decisions = set() if decisions is None else decisions
@@ -426,13 +435,24 @@ def _classify(env, got_alphas, or_alphas, got_obs, or_obs, S, K, textured, decis
     for o, y, x in torch.nonzero(dal > TOL).tolist():
         if o not in faces_cache:
             faces_cache[o] = _Faces(env.objs[o][0], env.objs[o][1], R, T)
-        hf = set()
-        why = explain_soft(faces_cache[o], S, y, x, K, hair_faces=hf)
+        hf, pf = set(), set()
+        why = explain_soft(faces_cache[o], S, y, x, K, hair_faces=hf, pair_faces=pf)
+        up = False
         if not why:
             why = upstream.explain(faces_cache[o], o, y, x, got_alphas[o, y, x])
+            up = bool(why)
         if why:
             ties[y, x] = True
-            decisions.update(("face", o, f) for f in hf) if HAIR in why else decisions.add(("pixel", y, x))
+            if REASON_LOG is not None:
+                REASON_LOG.append(("alpha", o, y, x, tuple(why)))
+            if up:
+                decisions.add(("upstream", o, y, x))
+            elif HAIR in why:
+                decisions.update(("face", o, f) for f in hf)
+            elif why == [PAIR]:
+                decisions.update(("pair", o, f) for f in pf)
+            else:
+                decisions.add(("pixel", y, x))
         else:
             unexplained.append(("alpha", o, y, x, float(dal[o, y, x])))
     dch = (or_obs - got_obs).abs()
@@ -447,6 +467,8 @@ def _classify(env, got_alphas, or_alphas, got_obs, or_obs, S, K, textured, decis
             why = explain_texel(env, S, y, x)
         if why:
             ties[y, x] = True
+            if REASON_LOG is not None:
+                REASON_LOG.append(("obs", -1, y, x, tuple(why)))
             decisions.update(("face", -1, f) for f in hf) if HAIR in why else decisions.add(("pixel", y, x))
         else:
             unexplained.append(("obs", -1, y, x, float(dob[y, x])))
@@ -468,7 +490,7 @@ def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_
     S, K = img, faces_per_pixel
     envs = list(check_envs if check_envs is not None else range(n_env))
     textured = mesh == "textured"
-    orc, weights, unexplained, n_ties, n_dec = {}, torch.ones(n_env, S, S), [], 0, 0
+    orc, weights, unexplained, n_ties, n_dec, n_up = {}, torch.ones(n_env, S, S), [], 0, 0, 0
     for i in envs:
         dec = set()
         env = oracle_env(case, i, img, shader, faces_per_pixel)
@@ -490,7 +512,8 @@ def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_
         unexplained += [(i, "reset") + u for u in u0] + [(i, "step") + u for u in u1]
         weights[i] = (~ties).float()
         n_ties = max(n_ties, int(ties.sum()))
-        n_dec = max(n_dec, len(dec))
+        n_dec = max(n_dec, sum(1 for d in dec if d[0] != "upstream"))
+        n_up = max(n_up, sum(1 for d in dec if d[0] == "upstream"))
         orc[i] = dict(env=env, obs0=obs0[0].detach(), al0=al0, img0=img0, a=a, obs=obs[0].detach(), al=al, ties=ties,
                       t0=t0, t1=t1, render=rnd)
     if n_ties:  # leave the tie pixels out of the loss on the GPU side too
@@ -499,7 +522,7 @@ def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_
         got_w = got
     res = dict(obs_maxabs=0.0, obs0_maxabs=0.0, alpha_maxabs=0.0, alpha0_maxabs=0.0, fs_maxabs=0.0, loss_rel=0.0,
                loss0_rel=0.0, reward_abs=0.0, grad_rel=0.0, grad_excess=0.0, grad_arbiter=[], render_maxabs=0.0,
-               tie_pixels=n_ties, tie_decisions=n_dec, unexplained=unexplained, img=img)
+               tie_pixels=n_ties, tie_decisions=n_dec, upstream_pixels=n_up, fs_arith=0.0, unexplained=unexplained, img=img)
     for i in envs:
         o = orc[i]
         env, keep0, keep1, keep = o["env"], ~o["t0"], ~o["t1"], ~o["ties"]
@@ -507,11 +530,20 @@ def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_
         res["obs0_maxabs"] = max(res["obs0_maxabs"], float(((o["obs0"] - got["obs0"][i]).abs() * keep0).max()))
         res["alpha_maxabs"] = max(res["alpha_maxabs"], float(((o["al"] - got["alphas"][i]).abs() * keep1).max()))
         res["alpha0_maxabs"] = max(res["alpha0_maxabs"], float(((o["al0"] - got["alphas0"][i]).abs() * keep0).max()))
-        # the occlusion image is a sum of three products of alphas, 0 ... 3: 1e-4 of its magnitude where that exceeds 1
+        # The occlusion image I = a1 a2 + a2 a3 + a1 a3 (channel 3; RGB = 3) is DERIVED from the alphas: alphas within
+        # 1e-4 only bound it to sum_i |d a_i| (a_j + a_k) <= 1e-4 * 2 (a1 + a2 + a3).  Two checks instead of one blunt one:
+        # (a) the combine kernel's arithmetic - the engine's image against I formed from the ENGINE's own alphas, every
+        # pixel, 1e-6; (b) against the oracle with that first-order bound of a 1e-4 error per alpha.
+        def occl(a):
+            return a[0] * a[1] + a[1] * a[2] + a[0] * a[2]
+
         fs_or = env.image[0].detach()
-        res["fs_maxabs"] = max(res["fs_maxabs"],
-                               float(((fs_or - got["fs"][i]).abs() / fs_or.abs().clamp(min=1.0) * keep1[..., None]).max()),
-                               float(((o["img0"][0] - got["fs0"][i]).abs() / o["img0"][0].abs().clamp(min=1.0) * keep0[..., None]).max()))
+        for fs_g, al_g, fs_o, al_o, keep_ in ((got["fs"][i], got["alphas"][i], fs_or, o["al"], keep1),
+                                              (got["fs0"][i], got["alphas0"][i], o["img0"][0], o["al0"], keep0)):
+            res["fs_arith"] = max(res["fs_arith"], float((fs_g[..., 3] - occl(al_g)).abs().max()),
+                                  float((fs_g[..., :3] - 3.0).abs().max()))
+            scale = (2.0 * al_o.sum(0)).clamp(min=1.0)
+            res["fs_maxabs"] = max(res["fs_maxabs"], float(((fs_o[..., 3] - fs_g[..., 3]).abs() / scale * keep_).max()))
         if o["render"] is not None:
             res["render_maxabs"] = max(res["render_maxabs"], float(((o["render"] - got["render"][i]).abs() * keep1).max()))
         # loss / reward / gradient with the tie pixels weighted out (environment.py:381-392 restated on the images)
@@ -575,6 +607,12 @@ def max_tie_pixels(img, n_objects=3):
     return max(4, int(2e-4 * img * img * n_objects))
 
 
+def max_upstream_pixels(img, n_objects=3):
+    """Bound on the pixels accepted through the near / z-clipped rule per env (each passed the rule's three machine
+    checks): with the camera inside an object a cut edge parallel to the clip plane moves along its whole length."""
+    return max(8, int(2e-3 * img * img * n_objects))
+
+
 def violations(res, tol=TOL):
     """What the parity tests, smoke() and scripts/parity_sweep.py all check; returns a list of failures (empty = ok)."""
     bad = []
@@ -582,8 +620,12 @@ def violations(res, tol=TOL):
         bad.append("unexplained pixels: %s" % (res["unexplained"][:6],))
     if res.get("tie_decisions", res["tie_pixels"]) > max_tie_pixels(res["img"]):
         bad.append("too many tie pixels: %d (%d decisions)" % (res["tie_pixels"], res.get("tie_decisions", -1)))
-    if res["tie_pixels"] > 8 * max_tie_pixels(res["img"]):  # footprints of hair-flipped needles included
+    if res.get("upstream_pixels", 0) > max_upstream_pixels(res["img"]):
+        bad.append("too many pixels under the near / z-clipped rule: %d" % res["upstream_pixels"])
+    if res["tie_pixels"] > 8 * max_tie_pixels(res["img"]) + max_upstream_pixels(res["img"]):  # footprints of hair-flipped needles included
         bad.append("too many tie pixels: %d" % res["tie_pixels"])
+    if not res.get("fs_arith", 0.0) < 1e-6:
+        bad.append("fs_arith = %.3e" % res["fs_arith"])
     for k in ("obs_maxabs", "obs0_maxabs", "alpha_maxabs", "alpha0_maxabs", "fs_maxabs", "render_maxabs", "loss_rel",
               "loss0_rel", "reward_abs"):
         if not res[k] < tol:

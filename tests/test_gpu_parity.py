@@ -90,6 +90,8 @@ def test_round1_sweep_misses_are_exact_ties(seed, mesh, img, az, radius):
     (4296, "teapot", 128, 50, 0.6, 2.5),     # wide sweep: camera inside object 3, z-clipped faces, alpha 5.9e-4
     (4312, "teapot", 128, 8, 0.6, 2.5),      # wide sweep: the same with K = 8, one half of a split face invisible
     (4317, "synthetic", 160, 8, 3.0, 2.5),   # wide sweep: near faces, K = 8
+    (5060, "teapot", 96, 50, 0.6, 2.5),      # wide sweep 2: occlusion image off by 1.4e-4 of 3 with every alpha within 8.7e-5
+    (5116, "teapot", 160, 50, 0.6, 1.3),     # wide sweep 2: one degenerate z-clipped pair, its halves tied along 39 pixels
 ])
 def test_round3_sweep_finds_are_conditioning_not_errors(seed, mesh, img, K, az, radius):
     """What the round-3 sweeps flagged under the then-frozen classifier (profiles/r03_parity_sweep2.txt, _wide.txt),
