@@ -1,6 +1,8 @@
 """Randomised parity sweep (GPU box): many seeded scenes through the HIP engine and the CPU oracle.
     python scripts/parity_sweep.py [n_seeds [first_seed [wide]]]     -> one line per case + a summary; exit 1 on a violation.
 "wide" also varies K (100 / 50 / 8 faces per pixel), the image side (64 ... 160) and the camera distance (1.3 ... 6).
+"stage" (wide cases) checks the RASTER STAGE ALONE: the oracle's rasteriser + blend run on the engine's own face records
+(identical geometry, no projection noise between the sides) against the engine's silhouettes, at 1e-5, no classifier.
 A case is "ok" under EXACTLY the criterion of the parity tests (tests/parity_utils.py: violations): 1e-4 everywhere,
 every pixel beyond it an oracle-verified exact tie, loss / reward / gradient at 1e-4 with the ties weighted out."""
 import os
@@ -28,9 +30,37 @@ def case_of_wide(seed):
     return dict(n_env=2, img=img, seed=seed, mesh=mesh, az_range=(0.6, 3.0)[seed % 2], radius=radius, faces_per_pixel=K)
 
 
+def stage_sweep(n, base):
+    import torch
+
+    from tests.parity_utils import alpha_of_records, make_case, run_engine
+
+    t0, tot_beyond, tot_pix, worst_rest, cases_beyond = time.time(), 0, 0, 0.0, 0
+    for seed in range(base, base + n):
+        c = case_of_wide(seed)
+        K = c["faces_per_pixel"]
+        got = run_engine(make_case(c["n_env"], seed, c["mesh"], c["az_range"]), c["img"], radius=c["radius"], faces_per_pixel=K)
+        beyond, rest, npx = 0, 0.0, 0
+        for phase, al in (("records0", got["alphas0"]), ("records", got["alphas"])):
+            for eo, rec in enumerate(got[phase]):
+                d = (alpha_of_records(rec, c["img"], K) - al[eo // 3, eo % 3]).abs()
+                beyond += int((d > 1e-5).sum())
+                rest = max(rest, float(torch.where(d > 1e-5, torch.zeros(()), d).max()))
+                npx += d.numel()
+        tot_beyond, tot_pix, worst_rest = tot_beyond + beyond, tot_pix + npx, max(worst_rest, rest)
+        cases_beyond += 1 if beyond else 0
+        print("seed %d %-9s %3d K %3d r %.1f  pixels beyond 1e-5: %d of %d  (largest of the others %.1e)" % (
+            seed, c["mesh"], c["img"], K, c["radius"], beyond, npx, rest), flush=True)
+    print("stage sweep: cases %d  object-pixels %d  beyond 1e-5: %d (in %d cases: depth ties at a K boundary)  largest of the others %.2e  %.0f s" % (
+        n, tot_pix, tot_beyond, cases_beyond, worst_rest, time.time() - t0))
+    return 0 if tot_beyond <= 3 * n else 1
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     base = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    if len(sys.argv) > 3 and sys.argv[3] == "stage":
+        sys.exit(stage_sweep(n, base))
     wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
     worst, bad, ties, t0 = {}, 0, 0, time.time()
     for seed in range(base, base + n):
