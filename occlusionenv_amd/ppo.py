@@ -84,7 +84,9 @@ class ActorCriticHeads(nn.Module):
 
 
 class BatchedPPO:
-    """PPO (PPO.py:107-223) over batched rollouts.  Hyper-parameters default to trainRL.py:42-56."""
+    """PPO (PPO.py:107-223) over batched rollouts.  Hyper-parameters default to trainRL.py:42-56.
+    ``fused`` (default on the GPU): the epochs of ``update`` run in the library (``occ_ppo_update``); the Adam moments and
+    step count then live in ``_fused_state`` (``optimizer`` only supplies the learning rates, betas and eps)."""
 
     def __init__(self, lr_actor: float = 3e-4, lr_critic: float = 1e-3, gamma: float = 0.99, K_epochs: int = 80,
                  eps_clip: float = 0.2, action_std_init: float = 0.6, device=None, seed: Optional[int] = None,
@@ -244,6 +246,18 @@ class BatchedPPO:
         # NB the total is not monotone: the advantages (returns - value) are re-evaluated with the improving critic
         return dict(loss_first=float(losses[0]), loss_last=float(losses[-1]), value_loss_first=float(vlosses[0]),
                     value_loss_last=float(vlosses[-1]), samples=samples)
+
+
+    # ---- checkpoints (PPO.py:225-230: the old policy's weights, loaded into both) -------------
+    def save(self, checkpoint_path) -> None:
+        torch.save(self.policy_old.state_dict(), checkpoint_path)
+
+    def load(self, checkpoint_path) -> None:
+        dev = next(self.policy.parameters()).device
+        sd = torch.load(checkpoint_path, map_location=dev)
+        self.policy_old.load_state_dict(sd)
+        self.policy.load_state_dict(sd)
+        self.action_std = float(self.policy.action_var[0].sqrt())
 
 
 def train_rollouts(venv, agent: BatchedPPO, n_updates: int = 1, T: int = 50, with_action_grad: bool = False,

@@ -33,8 +33,22 @@ def case_of_wide(seed):
 def stage_sweep(n, base):
     import torch
 
-    from tests.parity_utils import alpha_of_records, make_case, run_engine
+    import collections
 
+    import numpy as np
+
+    from tests.parity_utils import alpha_of_records, explain_soft, make_case, run_engine
+
+    class _RecFaces:  # the engine's records in the shape explain_soft expects of the oracle's faces
+        def __init__(self, rec):
+            self.fv, self.c2u = rec["fv"].float().contiguous(), None
+            fl, idx = rec["flags"], np.arange(rec["fv"].shape[0])
+            nb = np.full(idx.shape[0], -1, dtype=np.int64)
+            nb[(fl & 1) != 0] = idx[(fl & 1) != 0] + 1
+            nb[(fl & 2) != 0] = idx[(fl & 2) != 0] - 1
+            self.nb = torch.from_numpy(nb)
+
+    reasons = collections.Counter()
     t0, tot_beyond, tot_pix, worst_rest, cases_beyond = time.time(), 0, 0, 0.0, 0
     for seed in range(base, base + n):
         c = case_of_wide(seed)
@@ -45,6 +59,9 @@ def stage_sweep(n, base):
             for eo, rec in enumerate(got[phase]):
                 d = (alpha_of_records(rec, c["img"], K) - al[eo // 3, eo % 3]).abs()
                 beyond += int((d > 1e-5).sum())
+                for y, x in torch.nonzero(d > 1e-5).tolist():  # every outlier must be a near-tie of the records' own geometry
+                    why = explain_soft(_RecFaces(rec), c["img"], y, x, K)
+                    reasons[tuple(why) if why else ("UNEXPLAINED",)] += 1
                 rest = max(rest, float(torch.where(d > 1e-5, torch.zeros(()), d).max()))
                 npx += d.numel()
         tot_beyond, tot_pix, worst_rest = tot_beyond + beyond, tot_pix + npx, max(worst_rest, rest)
@@ -53,7 +70,8 @@ def stage_sweep(n, base):
             seed, c["mesh"], c["img"], K, c["radius"], beyond, npx, rest), flush=True)
     print("stage sweep: cases %d  object-pixels %d  beyond 1e-5: %d (in %d cases: depth ties at a K boundary)  largest of the others %.2e  %.0f s" % (
         n, tot_pix, tot_beyond, cases_beyond, worst_rest, time.time() - t0))
-    return 0 if tot_beyond <= 3 * n else 1
+    print("reasons of the pixels beyond 1e-5 (tie classifier of tests/parity_utils.py on the records' own geometry):", dict(reasons))
+    return 0 if tot_beyond <= 3 * n and not reasons.get(("UNEXPLAINED",), 0) else 1
 
 
 if __name__ == "__main__":

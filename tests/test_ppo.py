@@ -68,3 +68,19 @@ def test_update_trains_heads_and_syncs_old_policy():
     assert agent.records == []
     agent.decay_action_std(0.05, 0.1)
     assert abs(agent.action_std - 0.55) < 1e-6 and torch.allclose(agent.policy_old.action_var, torch.full((2,), 0.55 ** 2))
+
+
+def test_save_and_load_round_trip(tmp_path):
+    """PPO.save / PPO.load (PPO.py:225-230): the old policy's weights, restored into both policies."""
+    a = ppo.BatchedPPO(K_epochs=2, seed=0)
+    a.set_action_std(0.4)
+    with torch.no_grad():
+        for p in a.policy_old.parameters():
+            p.add_(0.25)
+    path = tmp_path / "ppo.pth"
+    a.save(path)
+    b = ppo.BatchedPPO(K_epochs=2, seed=1)
+    b.load(path)
+    for k, v in a.policy_old.state_dict().items():
+        assert torch.equal(b.policy.state_dict()[k], v) and torch.equal(b.policy_old.state_dict()[k], v)
+    assert abs(b.action_std - 0.4) < 1e-6
