@@ -45,6 +45,7 @@ def test_binding_constants_match_header():
     assert define("OCC_LOG_CAP") == nat.LOG_CAP and define("OCC_LOG_ENTRY_BYTES") == nat.LOG_ENTRY_BYTES and define("OCC_MAX_K") == nat.MAX_K
     assert (define("OCC_RENDER_SOFT"), define("OCC_RENDER_HARD"), define("OCC_RENDER_GRAD")) == (1, 2, 4)
     assert (define("OCC_CAM_STEP"), define("OCC_CAM_LOOKAT"), define("OCC_CAM_POSITION")) == (0, 1, 2)
+    assert define("OCC_PPO_FEATURES") == nat.PPO_FEATURES and define("OCC_PPO_MAX_BLOCKS") * (nat.PPO_PARAMS + 2) == nat.PPO_SCRATCH_FLOATS
 
 
 def test_workspace_query_and_argument_checks_need_no_gpu():
@@ -75,3 +76,13 @@ def test_workspace_query_and_argument_checks_need_no_gpu():
     assert lib.occ_step_flags(None, None, None, 4, 0, None, None) == 1
     assert lib.occ_reset_commit(None, 2, *([None] * 13), 64, None) == 1
     assert lib.occ_reset_commit(None, 0, *([None] * 13), 64, None) == 0  # nothing to commit
+    # the learner's entry points: null pointers, a pooling grid that does not divide the image, a non-positive variance
+    assert lib.occ_pool8(None, 4, 128, None, None) == 1
+    assert lib.occ_pool8(ctypes.c_void_p(16), 4, 100, ctypes.c_void_p(16), None) == 1
+    st = nat.OccPpoState()
+    assert lib.occ_ppo_update(None, None, None, None, 8, 0.36, 0.2, 3e-4, 1e-3, 0.9, 0.999, 1e-8, ctypes.byref(st), 1, None, None,
+                              None, None) == 1
+    p16 = ctypes.c_void_p(16)
+    assert lib.occ_ppo_update(p16, p16, p16, p16, 8, 0.0, 0.2, 3e-4, 1e-3, 0.9, 0.999, 1e-8, ctypes.byref(st), 1, p16, p16, p16,
+                              None) == 1  # variance 0 / state pointers unset
+    assert (nat.PPO_FEATURES, nat.PPO_PARAMS) == (256, 771)
