@@ -1,5 +1,7 @@
 """Batched PPO learner counterpart against the reference's algorithm restated inline
 (/root/reference/PPO.py:62-104,176-217)."""
+import math
+
 import torch
 from torch.distributions import MultivariateNormal
 
@@ -84,3 +86,50 @@ def test_save_and_load_round_trip(tmp_path):
     for k, v in a.policy_old.state_dict().items():
         assert torch.equal(b.policy.state_dict()[k], v) and torch.equal(b.policy_old.state_dict()[k], v)
     assert abs(b.action_std - 0.4) < 1e-6
+
+
+def test_closed_form_epoch_gradients_equal_autograd():
+    """The formulas that csrc/occ_ppo.hpp implements (its header comment), written out in numpy-style torch without
+    autograd, against torch autograd of the loss of PPO.py:199-212 - on the CPU, so that the kernel's arithmetic is pinned
+    independently of the GPU test that compares the kernel itself with the torch epochs.  Includes samples whose ratio is
+    clipped from above and from below with either sign of the advantage (the four branches of min / clamp)."""
+    g = torch.Generator().manual_seed(11)
+    M, F_ = 400, 256
+    feats = torch.rand(M, F_, generator=g)
+    heads = ppo.ActorCriticHeads(action_std_init=0.5)
+    with torch.no_grad():
+        heads.action_head.weight.mul_(3.0)
+    actions = torch.randn(M, 2, generator=g) * 0.7
+    old_lp = -1.2 + 0.8 * torch.randn(M, generator=g)        # wide spread: many ratios outside [0.8, 1.2]
+    returns = torch.randn(M, generator=g)
+    eps_clip = 0.2
+    # autograd
+    lp, value, ent = heads.evaluate(feats, actions)
+    ratios = torch.exp(lp - old_lp)
+    adv = returns - value.detach()
+    surr1, surr2 = ratios * adv, torch.clamp(ratios, 1 - eps_clip, 1 + eps_clip) * adv
+    vloss = torch.mean((value - returns) ** 2)
+    loss = (-torch.min(surr1, surr2) + 0.5 * vloss - 0.01 * ent).mean()
+    loss.backward()
+    # closed form
+    with torch.no_grad():
+        var = float(heads.action_var[0])
+        mean = feats @ heads.action_head.weight.t() + heads.action_head.bias
+        val = feats @ heads.value_head.weight.t().squeeze(1) + heads.value_head.bias
+        e = actions - mean
+        lp_c = -0.5 * (e * e).sum(1) / var - 0.5 * (2 * ppo.LOG_2PI + 2 * math.log(var))
+        ratio = torch.exp(lp_c - old_lp)
+        adv_c = returns - val
+        lo, hi = 1 - eps_clip, 1 + eps_clip
+        s1, s2 = ratio * adv_c, ratio.clamp(lo, hi) * adv_c
+        through = ((ratio >= lo) & (ratio <= hi)) | (s1 < s2)
+        assert int((~through).sum()) > 20 and int(((ratio > hi) & through).sum()) > 5 and int(((ratio < lo) & through).sum()) > 5
+        dlp = torch.where(through, -adv_c * ratio / M, torch.zeros(()))
+        gm = dlp[:, None] * e / var                           # d loss / d mean
+        gval = (val - returns) / M
+        loss_c = (-torch.minimum(s1, s2)).mean() + 0.5 * ((val - returns) ** 2).mean() - 0.01 * 0.5 * (2 * (1 + ppo.LOG_2PI) + 2 * math.log(var))
+    assert abs(float(loss_c) - float(loss)) < 1e-5
+    assert torch.allclose(gm.t() @ feats, heads.action_head.weight.grad, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(gm.sum(0), heads.action_head.bias.grad, rtol=1e-4, atol=1e-6)
+    assert torch.allclose((gval[:, None] * feats).sum(0, keepdim=True), heads.value_head.weight.grad, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(gval.sum().reshape(1), heads.value_head.bias.grad, rtol=1e-4, atol=1e-6)
