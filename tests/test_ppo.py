@@ -128,7 +128,7 @@ def test_closed_form_epoch_gradients_equal_autograd():
         gm = dlp[:, None] * e / var                           # d loss / d mean
         gval = (val - returns) / M
         loss_c = (-torch.minimum(s1, s2)).mean() + 0.5 * ((val - returns) ** 2).mean() - 0.01 * 0.5 * (2 * (1 + ppo.LOG_2PI) + 2 * math.log(var))
-    assert abs(float(loss_c) - float(loss)) < 1e-5
+    assert abs(float(loss_c) - float(loss.detach())) < 1e-5
     assert torch.allclose(gm.t() @ feats, heads.action_head.weight.grad, rtol=1e-4, atol=1e-6)
     assert torch.allclose(gm.sum(0), heads.action_head.bias.grad, rtol=1e-4, atol=1e-6)
     assert torch.allclose((gval[:, None] * feats).sum(0, keepdim=True), heads.value_head.weight.grad, rtol=1e-4, atol=1e-6)
