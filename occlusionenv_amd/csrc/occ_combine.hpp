@@ -16,6 +16,39 @@ __global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bp
     const int yi = live ? pix / S : 0, xi = live ? pix - (pix / S) * S : 0;
     const int tx = xi / OCC_BLOCK, ty = yi / OCC_BLOCK;
     const int cap = P.sc.rec_cap;
+#ifndef OCC_NO_BG_FASTPATH
+    {
+        // BACKGROUND BLOCKS (three quarters of them in the bench workload): none of the block's 256 consecutive pixels
+        // lies in any object's rect - nothing to read, the outputs are constants.  Written with one 16-byte store per
+        // thread and array (a pixel-per-thread block issues eight 4-byte plane stores); same values as the path below.
+        const int p0 = blk * 256, p1 = p0 + 255;
+        bool bg = p1 < S * S;
+        const int r0 = p0 / S, r1 = p1 / S, c0 = p0 - r0 * S, c1 = c0 + 255;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const int eo = env * 3 + o;
+            ciptr rect = as_const(P.ws.objrect + eo * 4);
+            const bool hit = as_const(P.ws.nrec + eo)[0] > 0 && r1 >= rect[1] * OCC_BLOCK && r0 <= rect[3] * OCC_BLOCK + OCC_BLOCK - 1 &&
+                             (r0 != r1 || (c1 >= rect[0] * OCC_BLOCK && c0 <= rect[2] * OCC_BLOCK + OCC_BLOCK - 1));
+            bg = bg && !hit;
+        }
+        if (bg) {  // block-uniform
+            const size_t S2 = (size_t)S * S;
+            const int plane = tid >> 6, quad = tid & 63;
+            if (SOFT) {
+                if (tid == 0) reinterpret_cast<float4*>(P.ws.partials)[blockIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (P.out.full_state) reinterpret_cast<float4*>(P.out.full_state)[(size_t)env * S2 + pix] = make_float4(3.f, 3.f, 3.f, 0.f);
+                if (P.out.alphas && plane < 3)
+                    reinterpret_cast<float4*>(P.out.alphas + ((size_t)env * 3 + plane) * S2 + p0)[quad] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (HARD) {
+                const float v = plane < 3 ? 1.f : -1.f;  // white background, depth -1 (environment.py:378)
+                reinterpret_cast<float4*>(P.out.obs + ((size_t)env * 4 + plane) * S2 + p0)[quad] = make_float4(v, v, v, v);
+            }
+            return;
+        }
+    }
+#endif
     float alpha[3] = {0.f, 0.f, 0.f}, dae[3] = {0.f, 0.f, 0.f}, daa[3] = {0.f, 0.f, 0.f};
     float hz = 3.0e38f;
     int hrec = -1, hobj = 0;

@@ -184,7 +184,9 @@ def test_corner_cut_never_changes_a_bit():
     """The setup kernel marks corner pixels of a face's pixel box that lie beyond the blur disc of the face's own box
     (occ_setup.hpp: finish_tri) and the raster kernel leaves those (face, pixel) pairs out of its rounds.  They were
     never candidates: every output of a step equals, bit for bit, what the build without the cut computes (on scenes
-    whose tiles stay below the log capacity: an in-loop compaction, triggered by the pair count, regroups the sums)."""
+    whose tiles stay below the log capacity: an in-loop compaction, triggered by the pair count, regroups the sums).
+    The same build (libocc_hip_nocut.so) also lacks the combine kernel's background fast path (blocks outside every
+    object rect write their constants with 16-byte stores): the outputs of those pixels are the same constants."""
     import tempfile
 
     from tests.parity_utils import make_case, run_engine
