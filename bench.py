@@ -53,6 +53,10 @@ def parse_args(argv=None):
     ap.add_argument("--pool-models", type=int, default=1024, help="synthetic mesh pool size (SURVEY 8d: 1024, seed 1234)")
     ap.add_argument("--rollout-T", type=int, default=50, help="ppo_rollout: steps per update (trainRL.py:24,46)")
     ap.add_argument("--ppo-epochs", type=int, default=80, help="ppo_rollout: K_epochs (trainRL.py:49)")
+    ap.add_argument("--max-ep-len", type=int, default=50, help="ppo_rollout: episode time limit (trainRL.py:22), 0 = none")
+    ap.add_argument("--output-ring", type=int, default=3,
+                    help="persistent output sets used in turn (the step's obs / full_state are overwritten that many steps "
+                         "later; the combine kernel then writes only what changed); 0 = freshly allocated outputs every step")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
     args = ap.parse_args(argv)
     if args.envs is None:
@@ -306,6 +310,8 @@ def main(argv=None):
     scene_workload = "shapenet5k" if ppo_mode else args.workload
     venv, ds = build_env(scene_workload, args.envs, args.img, seed=42 + rank, pool_models=args.pool_models)
     eng = venv.engine
+    if args.output_ring and eng.R:
+        venv.use_output_ring(args.output_ring)
     # SURVEY.md §8d scene distribution: x2 ~ N(0,1) (np.random, seeded), az ~ U(-0.6, 0.6), el = 0; scenes pass
     # the reference's reset rejection loop (loss > 0.1, environment.py:327).  VecEnv.reset() itself draws
     # az ~ U(-40, 40) rad (SubProcVecEnv.py:233), which mostly yields non-occluding views that finish at once.
@@ -338,17 +344,28 @@ def main(argv=None):
 
         # replicated learner: same seed on every rank, same gathered records -> identical heads, no gradient collective
         agent = ppo_mod.BatchedPPO(device=dev, seed=0, K_epochs=args.ppo_epochs)
-        ppo_state.update(obs=obs0, updates=0, stats=None, rew=[])
+        ppo_state.update(obs=obs0, updates=0, stats=None, rew=[], pending=False, t=0)
+        if args.max_ep_len:  # trainRL.py:22,191-229: every episode ends in reset() after max_ep_len steps, done or not
+            venv.max_ep_len = args.max_ep_len
+            venv.stagger_ages(seed=11 + rank)
+        # the per-step record exchange on its own stream: the record of step t is stored while step t + 1 renders
+        pxch = rollout.RecordExchange(args.envs, dev, world, keep=True)
 
         def one_step():  # noqa: F811 - trainRL.py:196-216, batched
             feats, action, logprob = agent.select_action(ppo_state["obs"], gen)
             action = action.detach().requires_grad_(True)
             obs, rewards, dones, _infos = venv.step(action)
             rewards.sum().backward()  # differentiable-reward backward to the action (train_predict.py:52)
-            rec = rollout.pack_records(obs, action, logprob, rewards, dones, features=feats)  # PPO.py:158: the acting state's
-            agent.store(rollout.all_gather_records(rec))
+            if ppo_state["pending"]:
+                agent.store(pxch.wait())
+            pxch.submit(obs, action, logprob, rewards, dones, features=feats)  # PPO.py:158: the acting state's features
+            venv.obs_consumer_event = pxch.ready
+            ppo_state["pending"] = True
             ppo_state["obs"] = obs
-            if len(agent.records) >= args.rollout_T:
+            ppo_state["t"] += 1
+            if ppo_state["t"] >= args.rollout_T:
+                agent.store(pxch.wait())
+                ppo_state["pending"], ppo_state["t"] = False, 0
                 ppo_state["stats"] = agent.update()
                 ppo_state["updates"] += 1
             return action.grad
@@ -372,6 +389,7 @@ def main(argv=None):
         warm.update()
         del warm
         agent.records = []  # the timed region starts a fresh rollout
+        ppo_state["pending"], ppo_state["t"] = False, 0
     nat.check(lib.occ_profile_enable(1), "occ_profile_enable")
     barrier()
     trace = os.environ.get("OCC_BENCH_TRACE")
@@ -425,11 +443,18 @@ def main(argv=None):
                 valu = {"insts_per_launch": nv, "issue_ms": issue_ms, "frac_of_launch": issue_ms / avg_ms,
                         "model": f"SQ_INSTS_VALU x {VALU_CYCLES} cycles / ({SIMDS} SIMDs x {CLOCK_HZ / 1e9:.1f} GHz)",
                         "source": "profiles/%s (not collected in this run)" % prof}
-        what = (f"PPO rollout (T={args.rollout_T}, heads-only update of {args.ppo_epochs} epochs inside the timed region), "
-                if ppo_mode else "")
+        what = (f"PPO rollout (T={args.rollout_T}, heads-only update of {args.ppo_epochs} epochs inside the timed region"
+                + (f", episode time limit {args.max_ep_len} steps" if args.max_ep_len else "") + "), " if ppo_mode else "")
+        meshes = {"teapot": "3 x data/teapot.obj (2 464 faces) per env", "mixed": "3 meshes per env from a mixed 1 280 / 5 120 / 20 480-face pool",
+                  "shapenet5k": "3 ShapeNet-size (~5k-face) meshes per env"}[scene_workload]
+        collective = {"nccl": "RCCL", "gloo": "gloo (rehearsal: the ranks share devices, no RCCL)"}[args.dist_backend]
+        # SURVEY 8d "secondary accounting" (reported, not canonical): the fragments PyTorch3D's design materialises per
+        # env-step - 28 B x K x S^2 per soft render x 3 + 28 B x S^2 hard forward, 12 B x K x S^2 x 3 re-read backward
+        frag_step = (28.0 * 100 * 3 + 28.0 + 12.0 * 100 * 3) * args.img * args.img
+        ring_on = bool(args.output_ring and eng.R)
         out = {
             # BASELINE.json's metric is quoted at 128x128 (the default --img); other sizes say so
-            "metric": f"env steps/sec (batched renders) @{args.img}x{args.img}, 3 ShapeNet-size (~5k-face) meshes per env",
+            "metric": f"env steps/sec (batched renders) @{args.img}x{args.img}, {meshes}",
             "value": value,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -444,8 +469,10 @@ def main(argv=None):
             "config": {"workload": f"{args.workload}: {what}{args.envs} envs/GPU x {world} GPU, {args.img}x{args.img}, "
                                    f"3 objects/env drawn from a pool of {args.pool_models if ds is not None else 1} meshes "
                                    f"(seed 1234), K=100 soft x3 + hard RGB-D, forward + action gradient"
-                                   + (", + RCCL all-gather of 1044-B rollout records" if world > 1 else ""),
+                                   + (f", + {collective} all-gather of 1044-B rollout records" if world > 1 else "")
+                                   + (f"; outputs in a ring of {args.output_ring} persistent sets" if ring_on else "; fresh output tensors every step"),
                        "envs_per_gpu": args.envs, "img": args.img, "faces_per_pixel": 100, "pool_models": args.pool_models,
+                       "output_ring": args.output_ring if ring_on else 0, "collective_backend": args.dist_backend if world > 1 else None,
                        "sharding": f"env-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": raster_name, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -453,6 +480,11 @@ def main(argv=None):
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": b_launch, "avg_launch_ms": avg_ms,
                          "launches": launches.value, "valu": valu,
+                         "secondary": {"label": "materialised-fragments accounting of SURVEY 8d (what PyTorch3D's design moves; "
+                                                "NOT canonical, the fused path never materialises them)",
+                                       "bytes_per_env_step": frag_step, "bytes_per_launch": frag_step * args.envs,
+                                       "achieved": (frag_step * args.envs / (avg_ms * 1e-3) / 1e9) if launches.value else None,
+                                       "unit": "GB/s", "frac": (frag_step * args.envs / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if launches.value else None},
                          "note": "VALU/latency-bound rasterisation; compulsory bytes are ~1.47 MB/env-step (SURVEY 8d)"},
         }
         if ppo_mode:

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define OCC_ABI_VERSION 7
+#define OCC_ABI_VERSION 8
 
 /* return codes */
 #define OCC_OK 0
@@ -109,6 +109,10 @@ typedef struct OccScene {
      * shaders need pool_vnormals (sumV,3): [P3D] Meshes.verts_normals_packed() of every pool mesh. */
     int32_t shader;
     const float* pool_vnormals;
+    /* Largest vertex count of any pool mesh, a sizing hint: the setup kernel stages an object's (<= 4 096) world-space
+     * vertices in LDS once instead of gathering three corners per face from global memory; larger objects, or 0 here,
+     * keep the global gathers.  Results are identical either way. */
+    int32_t max_mesh_verts;
 } OccScene;
 
 /* Caller-allocated scratch; sizes from occ_workspace_query(). */
@@ -156,6 +160,20 @@ typedef struct OccWorkspaceSizes {
     size_t order_bytes;
 } OccWorkspaceSizes;
 
+/*
+ * Optional tail of a STEP launch: the reward bookkeeping of occ_step_finish (environment.py:381-392) done by the very
+ * launch that reduces the loss (one dependent launch less per step).  Rows [0, n_step) are stepping envs; rows beyond
+ * (reserve scenes riding along) only get their loss.
+ */
+typedef struct OccStepFinish {
+    float* full_reward;       /* (n_step) in/out */
+    const float* object_mass; /* (n_step) */
+    float* reward;            /* (n_step) out */
+    uint8_t* done;            /* (n_step) out, 0 / 1 */
+    float* grad_action;       /* (n_step,2) out or NULL; needs OccRenderOut.grad_elaz */
+    int32_t n_step;
+} OccStepFinish;
+
 /* Outputs of one batched render (device pointers; any may be NULL if the flag is off). */
 typedef struct OccRenderOut {
     float* obs;        /* (n_env,4,S,S)  RGB + view-space depth, -1 background (environment.py:376-378) */
@@ -163,7 +181,35 @@ typedef struct OccRenderOut {
     float* alphas;     /* (n_env,3,S,S)  alpha channel of the three silhouettes */
     float* loss;       /* (n_env)        sum(full_state[...,3]^2) (environment.py:381) */
     float* grad_elaz;  /* (n_env,2)      d loss / d(elevation, azimuth) */
+    /*
+     * Optional REGION TRACKING of persistent output buffers (an output ring, the alphas state): three quarters of a
+     * 128 x 128 frame are background, and a freshly allocated output has every one of those pixels written every step.
+     * rect_prev (n_env,4) int32 pixel rects x0,y0,x1,y1 (inclusive; x1 < x0 = empty): the caller GUARANTEES that obs and
+     * full_state of row e hold their background values (1,1,1,-1 / 3,3,3,0) everywhere outside rect_prev[e].  The
+     * launch then writes only the 256-pixel blocks that meet this step's object rects or rect_prev[e] and stores this
+     * step's union rect in rect_next[e] (skipped rows: rect_next = rect_prev).  NULL = every pixel is written.
+     * arect_prev / arect_next: the same for alphas (background 0).  prev and next must be different arrays.
+     */
+    const int32_t* rect_prev;
+    int32_t* rect_next;
+    const int32_t* arect_prev;
+    int32_t* arect_next;
+    const OccStepFinish* finish; /* host pointer, read during the call; NULL = loss / gradient only */
 } OccRenderOut;
+
+/* Optional head of a STEP launch: the camera update of occ_camera done by the launch's prologue kernel (one dependent
+ * launch less per step).  Arguments as occ_camera; cam_pos_out2 (n,3): a second copy of C (the step's info["position"]
+ * snapshot) or NULL. */
+typedef struct OccCameraArgs {
+    int32_t mode;
+    const float* action;
+    float* el;
+    float* az;
+    const float* radius;
+    float* cam_pos_out;
+    float* cam_pos_out2;
+    int32_t n;
+} OccCameraArgs;
 
 int occ_abi_version(void);
 
@@ -193,6 +239,12 @@ int occ_camera(int mode, const float* action, float* el, float* az, const float*
  * gradient) and the per-env reduction, for all envs. */
 int occ_render(const OccScene* scene, const float* cam, const OccWorkspace* ws,
                const OccRenderOut* out, int flags, int faces_per_pixel, void* stream);
+
+/* occ_render with the step's camera update folded into its prologue launch: rows [0, camera->n) of cam are written
+ * from (action, el, az, radius) first (OccCameraArgs; NULL = cam is ready, exactly occ_render).  Together with
+ * OccRenderOut.finish this is the whole of OcclusionEnv.step() (environment.py:352-396) for N envs in one call. */
+int occ_step(const OccScene* scene, const OccCameraArgs* camera, float* cam, const OccWorkspace* ws,
+             const OccRenderOut* out, int flags, int faces_per_pixel, void* stream);
 
 /*
  * Reward bookkeeping of step() (environment.py:381-392) for N envs:
@@ -320,7 +372,7 @@ int occ_reset_commit(const int32_t* pairs, int n, float* el, float* az, float* r
  * them and refreshes the skip mask (rendered next step = PENDING only); (2) every pair copies the slot's stored
  * state into the env's rows (as occ_reset_commit), saving the env's final observation to term_obs[slot] first
  * (info["terminal_observation"]).
- * report (n_env + 2*n_reserve + 2 int32): [0,n_env) done | [n_env, +n_reserve) slot state AFTER the call |
+ * report (n_env + 2*n_reserve + 2 int32): [0,n_env) 1 = done, 2 = time limit (OccAutoResetOpts) | [n_env, +n_reserve) slot state AFTER the call |
  * [.., +n_reserve) env that took the slot this call or -1 | any status bit | finished envs left without a slot.
  * pairs: scratch, 2 + 2*n_reserve int32.  Arrays of OccEnvState hold n_env + n_reserve rows except
  * campos / full_reward / object_mass (n_env rows); obs_all has n_env + n_reserve rows.
@@ -350,9 +402,27 @@ typedef struct OccReserveStore {
     int32_t* skip;     /* (n_env + n_reserve) the OccScene.skip mask; rows >= n_env maintained here */
 } OccReserveStore;
 
+/* Optional extras of occ_auto_reset (NULL = none of them). */
+typedef struct OccAutoResetOpts {
+    /* Episode time limit (trainRL.py:22,191-229: `for t in range(1, max_ep_len + 1)` then env.reset(), is_terminal stays
+     * False): age (n_env) = steps since the env's last reset, incremented by this call; an env whose age reaches
+     * max_ep_len (> 0) is reset from the reserve like a finished one, with done left 0 (report value 2); a committed
+     * env's age returns to 0.  age == NULL: no counting. */
+    int32_t* age;
+    int32_t max_ep_len;
+    /* Region-tracking rects of obs_all and of the alphas state (OccRenderOut.rect_next / arect_next of the launch that
+     * produced this step): a committed row holds a whole stored frame and is marked full-frame. */
+    int32_t* rect;
+    int32_t* arect;
+    /* (n_reserve,S,S,4): receives the stored occlusion image of every slot taken in this call (what the reference's
+     * env.image holds after reset(), environment.py:319). */
+    float* reset_full_state;
+} OccAutoResetOpts;
+
 int occ_auto_reset(const uint8_t* done, const float* loss_all, const int32_t* status, int n_env, int n_reserve,
                    int32_t* rs_state, int32_t* rs_tries, const OccEnvState* st, float* obs_all, const float* full_state_all,
-                   const OccReserveStore* store, float* term_obs, int img, int32_t* pairs, int32_t* report, void* stream);
+                   const OccReserveStore* store, float* term_obs, int img, int32_t* pairs, int32_t* report,
+                   const OccAutoResetOpts* opts, void* stream);
 
 /*
  * Host -> reserve: n packed rows of 13 words (slot, mesh id x3, offset x9 as float bits) already in device

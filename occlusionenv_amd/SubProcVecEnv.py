@@ -110,6 +110,16 @@ class _LazyInfos(Sequence):
 
 class SimpleVecEnv(VecEnv):
     def __init__(self, env_fns):
+        """``env_fns`` as the reference (SubProcVecEnv.py:191); the signature is the reference's.  Two opt-in extras are
+        attributes, both off by default:
+
+        ``venv.max_ep_len = 50``: the episode time limit of the reference's training loop (trainRL.py:22,191-229: an
+        episode ends in ``env.reset()`` after max_ep_len steps whether done or not, and ``is_terminal`` stays False):
+        an env that has stepped max_ep_len times since its last reset is reset like a finished one, with ``dones`` left
+        False and ``infos[i]["TimeLimit.truncated"] = True`` beside ``terminal_observation``.
+
+        ``venv.use_output_ring(k)`` (k >= 2): the engine's output ring (engine.OcclusionEngine): ``obs`` /
+        ``infos[i]["full_state"]`` of a step are views of one of k persistent output sets and are overwritten k steps later."""
         self.envs = [fn() for fn in env_fns]
         env = self.envs[0]
         VecEnv.__init__(self, len(env_fns), env.observation_space, env.action_space)
@@ -123,6 +133,8 @@ class SimpleVecEnv(VecEnv):
         # a generous N/8 slots cost next to nothing and keep the reserve far from running dry
         reserve = min(512, max(self.num_envs // 8, 2 if self.num_envs >= 16 else 0)) if same_data else 0
         self.engine = OcclusionEngine(shared_pool(dev), self.num_envs, env.img_size, device=dev, reserve=reserve)
+        self._age_host = np.zeros(self.num_envs, dtype=np.int64)  # the time limit's counters of the host-driven path (no reserve)
+        self.max_ep_len = None
         for i, e in enumerate(self.envs):
             e._attach(self.engine, i)
         self._rs_scene = [None] * reserve   # scene assigned to each reserve slot
@@ -130,7 +142,6 @@ class SimpleVecEnv(VecEnv):
         self._rs_state = np.zeros(reserve, dtype=np.int32)
         self._pending = None                # (report handle, obs, out, infos) of the last step, not yet read
         self._late = []                     # slots refilled AFTER the pairing of the step whose report is pending
-        self._taken_host, self._taken_flip = None, 0  # pinned staging of the slot indices (double-buffered)
         self._half = None                   # (report handle, infos, taken slots, their envs) of a report read by the
         #                                     fast half of _drain whose per-env bookkeeping has not run yet
         self._fin_recent = 0.0              # decaying maximum of the number of envs that finished in one step
@@ -141,6 +152,30 @@ class SimpleVecEnv(VecEnv):
 
     def step_async(self, actions):
         self.actions = actions
+
+    def use_output_ring(self, k: int) -> None:
+        """Switch the engine to k >= 2 persistent output sets (0: back to fresh tensors every step).  Needs the reserve
+        (>= 16 envs sharing one dataset): the ring lives on the whole-batch step path."""
+        self._drain()
+        eng = self.engine
+        if k and not eng.R:
+            raise ValueError("the output ring needs the batched step path with a reserve (>= 16 envs on one dataset)")
+        if k == 1 or k < 0:
+            raise ValueError("output ring: 0 (fresh outputs) or k >= 2 sets")
+        eng.output_ring, eng._ring, eng._ring_pos = int(k), None, 0
+
+    def stagger_ages(self, seed=None) -> None:
+        """Spread the envs' episode ages uniformly over [0, max_ep_len): envs that were reset together would otherwise
+        all reach the time limit in the same step (N simultaneous resets against a reserve of N/8 slots, i.e. the
+        synchronous fallback every max_ep_len steps); afterwards about N / max_ep_len expire per step.  A deviation of
+        the batched loop only: every env's FIRST episode is shorter than max_ep_len."""
+        if not self.max_ep_len:
+            return
+        self._drain()
+        g = torch.Generator().manual_seed(int(seed)) if seed is not None else None
+        ages = torch.randint(0, int(self.max_ep_len), (self.num_envs,), generator=g, dtype=torch.int32)
+        self.engine.age.copy_(ages)
+        self._age_host[:] = ages.numpy()
 
     def _refill_reserve(self, slots):
         """Draw a new candidate scene for the given (EMPTY) reserve slots on the host and hand them to the device."""
@@ -220,6 +255,8 @@ class SimpleVecEnv(VecEnv):
         took = assign[taken].astype(np.int64)  # env that took slot taken[j]
         eng.note_commits(took, taken)
         self._half = (pend, infos, taken.tolist(), took.tolist())
+        for i in np.nonzero(rep[:N] == 2)[0].tolist():  # reset by the time limit, not done (trainRL.py:191-229)
+            infos.set(i, "TimeLimit.truncated", True)
         if rep[N + 2 * R + 1]:  # reserve exhausted: synchronous batched reset for the rest
             self._drain_finish()
             done_envs = set(np.nonzero(rep[:N])[0].tolist())
@@ -230,6 +267,8 @@ class SimpleVecEnv(VecEnv):
             if self.obs_consumer_event is not None:
                 torch.cuda.current_stream(eng.device).wait_event(self.obs_consumer_event)
             obs[left] = self._reset_envs(left, torch.zeros(len(left)))[:, 0]
+            if out.get("rect") is not None:  # output ring: these rows of the set now hold whole frames
+                out["rect"][left] = torch.tensor([0, 0, eng.S - 1, eng.S - 1], dtype=torch.int32, device=eng.device)
         # slots refilled after this report's pairing ran still read EMPTY in it: they are PENDING by now
         state[self._late] = nat.RS_PENDING
         self._late = []
@@ -252,19 +291,12 @@ class SimpleVecEnv(VecEnv):
         if not taken:
             return
         eng = self.engine
-        # the slots' stored renders (they will be overwritten): ONE gather for all of them
-        # (indices through pinned memory: a pageable upload would make the host wait for the step just launched)
-        if self._taken_host is None:
-            self._taken_host = [torch.zeros(eng.R, dtype=torch.int64).pin_memory() for _ in range(2)]
-        self._taken_flip ^= 1
-        th = self._taken_host[self._taken_flip]
-        th.numpy()[:len(taken)] = taken
-        images = eng._res_fs[th[:len(taken)].to(eng.device, non_blocking=True)]
-        for j, (r, i) in enumerate(zip(taken, took)):
+        for r, i in zip(taken, took):
             # save final observation where user can get it, then reset (SubProcVecEnv.py:211-214)
             infos.set(i, "terminal_observation", pend["term"][r:r + 1])
             self.envs[i]._scene = self._rs_scene[r]
-            self.envs[i].image = images[j:j + 1]
+            # the slot's stored occlusion image, copied out by the commit itself (OccAutoResetOpts.reset_full_state)
+            self.envs[i].image = pend["reset_fs"][r:r + 1]
 
     def step_wait(self):
         eng = self.engine
@@ -285,9 +317,9 @@ class SimpleVecEnv(VecEnv):
             self._drain_finish()  # the rest of the previous step's report, now that this step is on its way
             # finished envs are reset ON THE DEVICE from the reserve (pairing + commit); the host reads the
             # report later (_drain).  NB out["obs_all"][:N] IS obs: the commit writes the reset observation in place
-            pos = eng.camera_position.clone()
+            eng.max_ep_len = int(self.max_ep_len or 0)
             pend = eng.auto_reset(out)
-            infos = _LazyInfos(pos, full_state, loss, resolve=self._drain)
+            infos = _LazyInfos(out["pos"], full_state, loss, resolve=self._drain)
             self._pending = (pend, obs, out, infos)
             # new candidate scenes for the slots emptied one step ago: off the critical path (the GPU is busy
             # with this step); they are rendered from the next step on
@@ -304,7 +336,14 @@ class SimpleVecEnv(VecEnv):
         fl = flags.cpu().numpy()
         if fl[-1]:
             eng.check_status()
-        fin_l = np.nonzero(fl[:N])[0].tolist()
+        fin = fl[:N] != 0
+        self._age_host += 1
+        if self.max_ep_len:  # the time limit (trainRL.py:191-229): reset, not done
+            expired = (self._age_host >= int(self.max_ep_len)) & ~fin
+            for i in np.nonzero(expired)[0].tolist():
+                infos.set(i, "TimeLimit.truncated", True)
+            fin = fin | expired
+        fin_l = np.nonzero(fin)[0].tolist()
         if fin_l:
             # save final observation where user can get it, then reset (SubProcVecEnv.py:211-214)
             term = obs[fin_l].clone()
@@ -324,6 +363,7 @@ class SimpleVecEnv(VecEnv):
         candidate -- the same outcome per env as trying them one by one, in far fewer GPU round trips."""
         self._drain()
         eng, N = self.engine, self.num_envs
+        self._age_host[list(indices)] = 0  # (the device-side counters: OcclusionEngine.commit_reset)
         az = torch.as_tensor(az, dtype=torch.float32).reshape(-1)
         pos = {i: j for j, i in enumerate(indices)}
         pending = list(indices)

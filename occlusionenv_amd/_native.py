@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OCC_HIP_LIB") or os.path.join(_HERE, "libocc_hip.so")
 
 # layout constants (must match include/occlusionenv_amd.h)
-ABI_VERSION = 7
+ABI_VERSION = 8
 CAM_STRIDE = 48
 REC_STRIDE = 32
 TILE = 8
@@ -48,6 +48,7 @@ class OccScene(C.Structure):
         ("pix_weight", C.c_void_p),
         ("shader", C.c_int32),
         ("pool_vnormals", C.c_void_p),
+        ("max_mesh_verts", C.c_int32),
     ]
 
 
@@ -98,6 +99,11 @@ class OccWorkspaceSizes(C.Structure):
     ]
 
 
+class OccStepFinish(C.Structure):
+    """The reward bookkeeping of occ_step_finish done by the launch that reduces the loss (OccRenderOut.finish)."""
+    _fields_ = [(n, C.c_void_p) for n in ("full_reward", "object_mass", "reward", "done", "grad_action")] + [("n_step", C.c_int32)]
+
+
 class OccRenderOut(C.Structure):
     _fields_ = [
         ("obs", C.c_void_p),
@@ -105,7 +111,23 @@ class OccRenderOut(C.Structure):
         ("alphas", C.c_void_p),
         ("loss", C.c_void_p),
         ("grad_elaz", C.c_void_p),
+        # region tracking of persistent outputs (include/occlusionenv_amd.h)
+        ("rect_prev", C.c_void_p),
+        ("rect_next", C.c_void_p),
+        ("arect_prev", C.c_void_p),
+        ("arect_next", C.c_void_p),
+        ("finish", C.POINTER(OccStepFinish)),
     ]
+
+
+class OccCameraArgs(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("action", C.c_void_p), ("el", C.c_void_p), ("az", C.c_void_p), ("radius", C.c_void_p),
+                ("cam_pos_out", C.c_void_p), ("cam_pos_out2", C.c_void_p), ("n", C.c_int32)]
+
+
+class OccAutoResetOpts(C.Structure):
+    _fields_ = [("age", C.c_void_p), ("max_ep_len", C.c_int32), ("rect", C.c_void_p), ("arect", C.c_void_p),
+                ("reset_full_state", C.c_void_p)]
 
 
 class OccEnvState(C.Structure):
@@ -139,6 +161,8 @@ SYMBOLS = {
                              C.c_int, C.c_void_p]),
     "occ_render": (C.c_int, [C.POINTER(OccScene), C.c_void_p, C.POINTER(OccWorkspace), C.POINTER(OccRenderOut),
                              C.c_int, C.c_int, C.c_void_p]),
+    "occ_step": (C.c_int, [C.POINTER(OccScene), C.POINTER(OccCameraArgs), C.c_void_p, C.POINTER(OccWorkspace),
+                           C.POINTER(OccRenderOut), C.c_int, C.c_int, C.c_void_p]),
     "occ_step_finish": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_void_p]),
     "occ_rasterize_meshes_naive": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                              C.c_int, C.c_int] + [C.c_void_p] * 5),
@@ -158,7 +182,7 @@ SYMBOLS = {
     "occ_reset_commit": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 13 + [C.c_int, C.c_void_p]),
     "occ_auto_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.POINTER(OccEnvState), C.c_void_p, C.c_void_p, C.POINTER(OccReserveStore), C.c_void_p,
-                                 C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                 C.c_int, C.c_void_p, C.c_void_p, C.POINTER(OccAutoResetOpts), C.c_void_p]),
     "occ_reserve_refill": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
     "occ_profile_enable": (C.c_int, [C.c_int]),

@@ -47,12 +47,11 @@ __device__ __forceinline__ void dcross(const D2* a, const D2* b, D2* o) {
     o[2] = a[0] * b[1] - a[1] * b[0];
 }
 
-__global__ __launch_bounds__(64) void occ_camera_kernel(int mode, const float* __restrict__ action,
-                                                        float* __restrict__ el_io, float* __restrict__ az_io,
-                                                        const float* __restrict__ radius, float* __restrict__ cam,
-                                                        float* __restrict__ cam_pos_out, int n_env) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= n_env) return;
+// camera of env n (one thread); pos2: optional second copy of C (the step's position snapshot)
+__device__ __forceinline__ void camera_one(int mode, const float* __restrict__ action, float* __restrict__ el_io,
+                                           float* __restrict__ az_io, const float* __restrict__ radius,
+                                           float* __restrict__ cam, float* __restrict__ cam_pos_out,
+                                           float* __restrict__ pos2, int n) {
     float* c = cam + (size_t)n * OCC_CAM_STRIDE;
     D2 C[3];
     float J[4] = {0.f, 0.f, 0.f, 0.f};
@@ -138,4 +137,18 @@ __global__ __launch_bounds__(64) void occ_camera_kernel(int mode, const float* _
         cam_pos_out[3 * n + 1] = C[1].v;
         cam_pos_out[3 * n + 2] = C[2].v;
     }
+    if (pos2) {
+        pos2[3 * n] = C[0].v;
+        pos2[3 * n + 1] = C[1].v;
+        pos2[3 * n + 2] = C[2].v;
+    }
+}
+
+__global__ __launch_bounds__(64) void occ_camera_kernel(int mode, const float* __restrict__ action,
+                                                        float* __restrict__ el_io, float* __restrict__ az_io,
+                                                        const float* __restrict__ radius, float* __restrict__ cam,
+                                                        float* __restrict__ cam_pos_out, int n_env) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_env) return;
+    camera_one(mode, action, el_io, az_io, radius, cam, cam_pos_out, nullptr, n);
 }

@@ -9,8 +9,35 @@ __global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bp
     __shared__ float s_red[4][3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int env = blockIdx.x / bpe, blk = blockIdx.x - env * bpe;
-    if (P.sc.skip && P.sc.skip[env]) return;  // outputs of a skipped scene row stay untouched
     const int S = P.sc.img;
+    // REGION TRACKING (OccRenderOut.rect_prev / arect_prev): outside those rects the persistent outputs already hold
+    // their background values, so only blocks that meet them or this step's object rects are written
+    const int32_t* __restrict__ rprev = (HARD || SOFT) ? P.out.rect_prev : nullptr;
+    const int32_t* __restrict__ aprev = SOFT ? P.out.arect_prev : nullptr;
+    if (P.sc.skip && P.sc.skip[env]) {  // outputs of a skipped scene row stay untouched - and so do their rects
+        if (blk == 0 && tid < 4) {
+            if (rprev && P.out.rect_next) P.out.rect_next[env * 4 + tid] = rprev[env * 4 + tid];
+            if (aprev && P.out.arect_next) P.out.arect_next[env * 4 + tid] = aprev[env * 4 + tid];
+        }
+        return;
+    }
+    if (blk == 0 && tid == 0 && (P.out.rect_next || P.out.arect_next)) {
+        // this step's footprint: the union of the object rects, in pixels (empty: x1 < x0)
+        int ux0 = S, uy0 = S, ux1 = -1, uy1 = -1;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const int eo = env * 3 + o;
+            ciptr rect = as_const(P.ws.objrect + eo * 4);
+            if (as_const(P.ws.nrec + eo)[0] > 0 && rect[2] >= rect[0] && rect[3] >= rect[1]) {
+                ux0 = min(ux0, rect[0] * OCC_BLOCK);
+                uy0 = min(uy0, rect[1] * OCC_BLOCK);
+                ux1 = max(ux1, rect[2] * OCC_BLOCK + OCC_BLOCK - 1);
+                uy1 = max(uy1, rect[3] * OCC_BLOCK + OCC_BLOCK - 1);
+            }
+        }
+        if (P.out.rect_next) reinterpret_cast<int4*>(P.out.rect_next)[env] = make_int4(ux0, uy0, ux1, uy1);
+        if (P.out.arect_next) reinterpret_cast<int4*>(P.out.arect_next)[env] = make_int4(ux0, uy0, ux1, uy1);
+    }
     const int pix = blk * 256 + tid;
     const bool live = pix < S * S;
     const int yi = live ? pix / S : 0, xi = live ? pix - (pix / S) * S : 0;
@@ -35,13 +62,20 @@ __global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bp
         if (bg) {  // block-uniform
             const size_t S2 = (size_t)S * S;
             const int plane = tid >> 6, quad = tid & 63;
+            // a tracked buffer is background here already unless the block meets what the buffer last held
+            auto meets = [&](const int32_t* __restrict__ rp) {
+                if (!rp) return true;
+                const int4 r = reinterpret_cast<const int4*>(rp)[env];  // x0, y0, x1, y1
+                return r1 >= r.y && r0 <= r.w && (r0 != r1 || (c1 >= r.x && c0 <= r.z));
+            };
+            const bool wo = meets(rprev), wa = meets(aprev);
             if (SOFT) {
                 if (tid == 0) reinterpret_cast<float4*>(P.ws.partials)[blockIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (P.out.full_state) reinterpret_cast<float4*>(P.out.full_state)[(size_t)env * S2 + pix] = make_float4(3.f, 3.f, 3.f, 0.f);
-                if (P.out.alphas && plane < 3)
+                if (P.out.full_state && wo) reinterpret_cast<float4*>(P.out.full_state)[(size_t)env * S2 + pix] = make_float4(3.f, 3.f, 3.f, 0.f);
+                if (P.out.alphas && plane < 3 && wa)
                     reinterpret_cast<float4*>(P.out.alphas + ((size_t)env * 3 + plane) * S2 + p0)[quad] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            if (HARD) {
+            if (HARD && wo) {
                 const float v = plane < 3 ? 1.f : -1.f;  // white background, depth -1 (environment.py:378)
                 reinterpret_cast<float4*>(P.out.obs + ((size_t)env * 4 + plane) * S2 + p0)[quad] = make_float4(v, v, v, v);
             }
@@ -250,9 +284,40 @@ __global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bp
 // ------------------------------------------------------------------------------------------
 // per-env fixed-order reduction of the tile partials
 // ------------------------------------------------------------------------------------------
+// reward rule of one env (environment.py:381-392) + action Jacobian (:356-361): shared by occ_finish_kernel and the
+// fused tail of occ_reduce_kernel
+__device__ __forceinline__ void finish_one(int n, float l, float gl_e, float gl_a, bool have_grad, const float* __restrict__ cam,
+                                           float* __restrict__ full_reward, const float* __restrict__ object_mass,
+                                           float* __restrict__ reward, uint8_t* __restrict__ done, float* __restrict__ grad_action) {
+    const float om = object_mass[n];
+    float rw = full_reward[n] - l;
+    full_reward[n] = l;
+    const bool fin = l < kDoneThreshold;
+    rw = rw / om;
+    rw = fin ? rw + kDoneBonus : rw - kStepPenalty;
+    reward[n] = rw;
+    done[n] = fin ? 1 : 0;
+    if (grad_action) {
+        float ga0 = 0.f, ga1 = 0.f;
+        if (have_grad) {
+            const float* __restrict__ J = cam + (size_t)n * OCC_CAM_STRIDE + C_J;
+            // d reward/d action_j = -(1/objectMass) * (dL/del * del/da_j + dL/daz * daz/da_j)
+            ga0 = -(gl_e * J[0] + gl_a * J[2]) / om;
+            ga1 = -(gl_e * J[1] + gl_a * J[3]) / om;
+        }
+        grad_action[2 * n] = ga0;
+        grad_action[2 * n + 1] = ga1;
+    }
+}
+
+struct FinishArgs {  // OccStepFinish by value (n_step = 0: no fused tail)
+    float* full_reward; const float* object_mass; float* reward; uint8_t* done; float* grad_action; const float* cam;
+    int n_step;
+};
+
 __global__ __launch_bounds__(64) void occ_reduce_kernel(const float* __restrict__ partials, int ntiles,
                                                         float* __restrict__ loss, float* __restrict__ grad_elaz,
-                                                        const int* __restrict__ skip) {
+                                                        const int* __restrict__ skip, FinishArgs fin) {
     const int env = blockIdx.x, lane = threadIdx.x;
     if (skip && skip[env]) return;
     const float4* __restrict__ p = reinterpret_cast<const float4*>(partials) + (size_t)env * ntiles;
@@ -272,6 +337,9 @@ __global__ __launch_bounds__(64) void occ_reduce_kernel(const float* __restrict_
             grad_elaz[2 * env] = ge;
             grad_elaz[2 * env + 1] = ga;
         }
+        if (env < fin.n_step)
+            finish_one(env, l, ge, ga, grad_elaz != nullptr, fin.cam, fin.full_reward, fin.object_mass, fin.reward, fin.done,
+                       fin.grad_action);
     }
 }
 
@@ -283,27 +351,8 @@ __global__ __launch_bounds__(64) void occ_finish_kernel(const float* __restrict_
                                                         int n_env) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_env) return;
-    const float l = loss[n];
-    const float om = object_mass[n];
-    float rw = full_reward[n] - l;
-    full_reward[n] = l;
-    const bool fin = l < kDoneThreshold;
-    rw = rw / om;
-    rw = fin ? rw + kDoneBonus : rw - kStepPenalty;
-    reward[n] = rw;
-    done[n] = fin ? 1 : 0;
-    if (grad_action) {
-        float ga0 = 0.f, ga1 = 0.f;
-        if (grad_elaz) {
-            const float* __restrict__ J = cam + (size_t)n * OCC_CAM_STRIDE + C_J;
-            const float gl_e = grad_elaz[2 * n], gl_a = grad_elaz[2 * n + 1];
-            // d reward/d action_j = -(1/objectMass) * (dL/del * del/da_j + dL/daz * daz/da_j)
-            ga0 = -(gl_e * J[0] + gl_a * J[2]) / om;
-            ga1 = -(gl_e * J[1] + gl_a * J[3]) / om;
-        }
-        grad_action[2 * n] = ga0;
-        grad_action[2 * n + 1] = ga1;
-    }
+    finish_one(n, loss[n], grad_elaz ? grad_elaz[2 * n] : 0.f, grad_elaz ? grad_elaz[2 * n + 1] : 0.f, grad_elaz != nullptr, cam,
+               full_reward, object_mass, reward, done, grad_action);
 }
 
 // One small int32 buffer per step for the host: [0..n) done, [n..n+r) reserve scene passes the reset test

@@ -217,7 +217,30 @@ static bool dbg_sync_on() {
 
 extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWorkspace* ws, const OccRenderOut* out,
                           int flags, int faces_per_pixel, void* stream) {
+    return occ_step(scene, nullptr, const_cast<float*>(cam), ws, out, flags, faces_per_pixel, stream);
+}
+
+extern "C" int occ_step(const OccScene* scene, const OccCameraArgs* camera, float* cam, const OccWorkspace* ws,
+                        const OccRenderOut* out, int flags, int faces_per_pixel, void* stream) {
     if (!scene_ok(scene) || !cam || !ws || !out) return OCC_ERR_ARG;
+    OccCameraArgs ca{};
+    if (camera) {
+        ca = *camera;
+        if (ca.n <= 0 || ca.n > scene->n_env || ca.mode < 0 || ca.mode > 2) return OCC_ERR_ARG;
+        if (ca.mode == OCC_CAM_STEP && (!ca.action || !ca.el || !ca.az || !ca.radius)) return OCC_ERR_ARG;
+        if (ca.mode == OCC_CAM_LOOKAT && (!ca.el || !ca.az || !ca.radius)) return OCC_ERR_ARG;
+        if (ca.mode == OCC_CAM_POSITION && !ca.action) return OCC_ERR_ARG;
+    }
+    if ((out->rect_prev != nullptr) != (out->rect_next != nullptr) || (out->rect_prev && out->rect_prev == out->rect_next)) return OCC_ERR_ARG;
+    if ((out->arect_prev != nullptr) != (out->arect_next != nullptr) || (out->arect_prev && out->arect_prev == out->arect_next)) return OCC_ERR_ARG;
+    FinishArgs fin{};
+    if (out->finish) {
+        const OccStepFinish& f = *out->finish;
+        if (!(flags & OCC_RENDER_SOFT) || !out->loss || !f.full_reward || !f.object_mass || !f.reward || !f.done || f.n_step <= 0 ||
+            f.n_step > scene->n_env || (f.grad_action && (flags & OCC_RENDER_GRAD) && !out->grad_elaz))
+            return OCC_ERR_ARG;
+        fin = FinishArgs{f.full_reward, f.object_mass, f.reward, f.done, f.grad_action, cam, f.n_step};
+    }
     if (!ws->rec || !ws->rec_bbox || !ws->nrec || !ws->objrect || !ws->queue || !ws->lists || !ws->partials ||
         !ws->status || !ws->rec_cbox || !ws->scan || !ws->offsets || !ws->obj_alpha || !ws->obj_grad || !ws->obj_hz || !ws->obj_hrec ||
         ws->n_slots <= 0)
@@ -233,13 +256,17 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
     if (ws->rec_off && (ws->rec_total <= 0 || (ws->rec_total & 63))) return OCC_ERR_ARG;
     static_assert(kOrdBlk <= 1024, "occ_recoff_kernel zeroes the order header with one block");
     // prologue: zero the queue heads and the order header, lay out the variable record spans
-    hipLaunchKernelGGL(occ_recoff_kernel, dim3(1), dim3(1024), 0, st, *scene, (long long*)ws->rec_off, (long long)ws->rec_total,
-                       ws->status, ws->queue, wsv.order);
+    hipLaunchKernelGGL(occ_recoff_kernel, dim3(1 + (ca.n + 1023) / 1024), dim3(1024), 0, st, *scene, (long long*)ws->rec_off,
+                       (long long)ws->rec_total, ws->status, ws->queue, wsv.order, ca, cam);
     OCC_DBG_SYNC("recoff");
+    // world-space vertices of an object staged in LDS when they fit (OccScene.max_mesh_verts; 0 = gather from global memory)
+    int vcap = scene->max_mesh_verts > 0 ? ((scene->max_mesh_verts + 63) & ~63) : 0;
+    if (vcap > kSetupVcapMax) vcap = kSetupVcapMax;
+    const size_t vlds = (size_t)vcap * 3 * sizeof(float);
     if (grad)
-        hipLaunchKernelGGL(occ_setup_kernel<true>, dim3(N * 3), dim3(256), 0, st, *scene, cam, wsv);
+        hipLaunchKernelGGL(occ_setup_kernel<true>, dim3(N * 3), dim3(256), vlds, st, *scene, cam, wsv, vcap);
     else
-        hipLaunchKernelGGL(occ_setup_kernel<false>, dim3(N * 3), dim3(256), 0, st, *scene, cam, wsv);
+        hipLaunchKernelGGL(occ_setup_kernel<false>, dim3(N * 3), dim3(256), vlds, st, *scene, cam, wsv, vcap);
     OCC_DBG_SYNC("setup");
     if (scene->rec_cap >= kSortMin) {
         // dense objects only: front-to-back scan order (LDS sort buffer: 8192 keys = 64 KiB)
@@ -302,7 +329,7 @@ extern "C" int occ_render(const OccScene* scene, const float* cam, const OccWork
     if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
     if (soft && (out->loss || out->grad_elaz)) {
         hipLaunchKernelGGL(occ_reduce_kernel, dim3(N), dim3(64), 0, st, ws->partials, bpe, out->loss,
-                           grad ? out->grad_elaz : nullptr, scene->skip);
+                           grad ? out->grad_elaz : nullptr, scene->skip, fin);
         if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
     }
     return OCC_OK;
@@ -468,7 +495,7 @@ extern "C" int occ_reset_commit(const int32_t* pairs, int n, float* el, float* a
 extern "C" int occ_auto_reset(const uint8_t* done, const float* loss_all, const int32_t* status, int n_env, int n_reserve,
                               int32_t* rs_state, int32_t* rs_tries, const OccEnvState* st, float* obs_all,
                               const float* full_state_all, const OccReserveStore* store, float* term_obs, int img,
-                              int32_t* pairs, int32_t* report, void* stream) {
+                              int32_t* pairs, int32_t* report, const OccAutoResetOpts* opts, void* stream) {
     if (!done || !loss_all || !status || n_env <= 0 || n_reserve <= 0 || n_reserve > 512 || !rs_state || !rs_tries || !st ||
         !obs_all || !full_state_all || !store || !term_obs || img < OCC_TILE || img % OCC_TILE || !pairs || !report)
         return OCC_ERR_ARG;
@@ -478,9 +505,13 @@ extern "C" int occ_auto_reset(const uint8_t* done, const float* loss_all, const 
     hipStream_t s = (hipStream_t)stream;
     StashArgs sa{rs_state, obs_all, full_state_all, loss_all, *store, img, n_env};
     hipLaunchKernelGGL(occ_stash_kernel, dim3(n_reserve, kStashBlocks), dim3(256), 0, s, sa);
-    PairArgs pa{done, loss_all, status, n_env, n_reserve, rs_state, rs_tries, pairs, report, store->skip};
+    OccAutoResetOpts o{};
+    if (opts) o = *opts;
+    if (o.max_ep_len > 0 && !o.age) return OCC_ERR_ARG;
+    PairArgs pa{done, loss_all, status, n_env, n_reserve, rs_state, rs_tries, pairs, report, store->skip, o.age, o.max_ep_len};
     hipLaunchKernelGGL(occ_pair_kernel, dim3(1), dim3(1024), 0, s, pa);
-    AutoCommitArgs ca{pairs, *st, obs_all, term_obs, store->obs, store->loss, img, n_env};
+    AutoCommitArgs ca{pairs, *st, obs_all, term_obs, store->obs, store->loss, img, n_env, o.age, o.rect, o.arect,
+                      store->full_state, o.reset_full_state};
     hipLaunchKernelGGL(occ_auto_commit_kernel, dim3(n_reserve, 1 + commit_obs_blocks(img) + commit_alpha_blocks(img)), dim3(256), 0, s, ca);
     return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
 }

@@ -8,6 +8,7 @@ struct PairArgs {
     const uint8_t* done; const float* loss_all; const int* status;
     int n_env, n_res;
     int* rs_state; int* rs_tries; int* pairs; int* report; int* skip;
+    int* age; int max_ep_len;  // episode time limit (trainRL.py:22,191-229): age (n_env) counts the steps since the last reset
 };
 
 // ordered compaction helper: exclusive prefix of flag over a 1024-thread block (16 waves)
@@ -55,9 +56,18 @@ __global__ __launch_bounds__(1024) void occ_pair_kernel(PairArgs a) {
     int nfin = 0, any = 0;
     for (int base = 0; base < N; base += 1024) {
         const int i = base + tid;
-        const bool f = i < N && a.done[i] != 0;
+        const bool fin = i < N && a.done[i] != 0;
+        // an env that has run max_ep_len steps since its reset is reset like a finished one, but NOT done (the reference's
+        // loop leaves `for t in range(1, max_ep_len + 1)` and calls env.reset(); is_terminal stays False)
+        bool expired = false;
+        if (i < N && a.age) {
+            const int ag = a.age[i] + 1;
+            a.age[i] = ag;
+            expired = a.max_ep_len > 0 && ag >= a.max_ep_len;
+        }
+        const bool f = fin || expired;
         if (i < N) {
-            a.report[i] = f ? 1 : 0;
+            a.report[i] = fin ? 1 : (expired ? 2 : 0);
             any |= a.status[i];
         }
         int tot;
@@ -122,6 +132,9 @@ struct AutoCommitArgs {
     OccEnvState st;
     float* obs_all; float* term_obs; const float* res_obs; const float* res_loss;
     int img, n_env;
+    int* age;                  // (n_env) or null: zeroed for the env that takes a slot
+    int* rect; int* arect;     // region-tracking rects of obs_all / the alphas state or null: the committed row is a full frame
+    const float* res_fs; float* reset_fs;  // stored occlusion image of the slot -> reset_fs[slot] (the env's image after reset) or null
 };
 // grid.y = 1 (state) + obs_blocks + alpha_blocks: the copies are sized by the image - a block moves ~4 x 256 float4 per
 // plane it touches (with the 8 + 6 blocks that were enough at 128 x 128 the commit of ONE env took 40 us at 256 x 256,
@@ -150,14 +163,23 @@ __global__ __launch_bounds__(256) void occ_auto_commit_kernel(AutoCommitArgs a) 
         }
         if (tid < 9) a.st.scene_offset[dst * 9 + tid] = a.st.scene_offset[src * 9 + tid];
         if (tid < OCC_CAM_STRIDE) a.st.cam[(size_t)dst * OCC_CAM_STRIDE + tid] = a.st.cam[(size_t)src * OCC_CAM_STRIDE + tid];
+        if (tid == 0 && a.age) a.age[dst] = 0;
+        if (tid < 4) {  // the row now holds a whole stored frame, not "background outside this step's footprint"
+            const int full = tid < 2 ? 0 : a.img - 1;
+            if (a.rect) a.rect[dst * 4 + tid] = full;
+            if (a.arect) a.arect[dst * 4 + tid] = full;
+        }
     } else if (y <= obs_blocks) {
         // final observation -> term_obs[slot], stored reset observation -> obs[env] (same element range, same thread)
         const float4* s4 = reinterpret_cast<const float4*>(a.res_obs + (size_t)(src - a.n_env) * 4 * S2);
         float4* d4 = reinterpret_cast<float4*>(a.obs_all + (size_t)dst * 4 * S2);
         float4* t4 = reinterpret_cast<float4*>(a.term_obs + (size_t)(src - a.n_env) * 4 * S2);
+        const float4* f4 = a.reset_fs ? reinterpret_cast<const float4*>(a.res_fs + (size_t)(src - a.n_env) * 4 * S2) : nullptr;
+        float4* g4 = a.reset_fs ? reinterpret_cast<float4*>(a.reset_fs + (size_t)(src - a.n_env) * 4 * S2) : nullptr;
         for (size_t i = (size_t)(y - 1) * 256 + tid; i < S2; i += (size_t)obs_blocks * 256) {
             t4[i] = d4[i];
             d4[i] = s4[i];
+            if (f4) g4[i] = f4[i];
         }
     } else {
         // (img is a multiple of 8: the three alpha planes are a whole number of float4)

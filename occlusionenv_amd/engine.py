@@ -48,7 +48,7 @@ class OcclusionEngine:
     """State + workspace of N environments on one GPU."""
 
     def __init__(self, pool: MeshPool, n_env: int, img_size: int, device=None, faces_per_pixel: int = 100,
-                 waves_per_cu: Optional[int] = None, reserve: int = 0, cost_order: bool = True):
+                 waves_per_cu: Optional[int] = None, reserve: int = 0, cost_order: bool = True, output_ring: int = 0):
         self.lib = nat.load()
         if not torch.cuda.is_available():
             raise nat.NativeError("OcclusionEngine needs a ROCm GPU (torch.cuda.is_available() is False); "
@@ -66,6 +66,18 @@ class OcclusionEngine:
         self.waves_per_cu = int(waves_per_cu or os.environ.get("OCC_WAVES_PER_CU", WAVES_PER_CU))
         # work items heaviest first (occ_order_kernel); False = plain rect order (OccWorkspace.order = NULL)
         self.cost_order = bool(cost_order)
+        # OUTPUT RING (opt-in; whole-batch steps with the reserve only).  0: every step returns freshly allocated
+        # obs / full_state tensors, every pixel of which the combine kernel writes (three quarters of a 128 x 128 frame
+        # are background constants).  k >= 2: k persistent output sets are used in turn and the kernel writes only the
+        # pixel blocks that meet this step's object rects or what the set held before (OccRenderOut.rect_prev): the
+        # tensors a step returns are overwritten k steps later - fine for rollout loops, which consume an observation
+        # before the next step (PPO.py:152-164), not for callers that keep observations around.
+        if output_ring == 1 or output_ring < 0:
+            raise ValueError("output_ring must be 0 (fresh outputs) or >= 2")
+        self.output_ring = int(output_ring)
+        self._ring, self._ring_pos = None, 0
+        # the setup kernel stages every object's vertices in LDS once (False: three global gathers per face; same results)
+        self.setup_vertex_lds = True
         d = self.device
         f32 = dict(dtype=torch.float32, device=d)
         N = self.N
@@ -88,6 +100,15 @@ class OcclusionEngine:
         self.camera_position = torch.zeros(N, 3, **f32)
         self.full_reward = torch.zeros(N, **f32)
         self.object_mass = torch.ones(N, **f32)
+        # episode time limit (trainRL.py:22,191-229): steps since the env's last reset, counted on the device by
+        # occ_auto_reset; max_ep_len = 0: no limit (the reference's SimpleVecEnv has none)
+        self.age = torch.zeros(N, dtype=torch.int32, device=d)
+        self.max_ep_len = 0
+        # region tracking of the persistent alphas state (OccRenderOut.arect_prev / arect_next): outside rect[e] the
+        # alphas of row e are zero.  Two arrays, flipped by every tracked launch; untracked writers mark rows full-frame.
+        self._arect = [torch.tensor([self.S, self.S, -1, -1], dtype=torch.int32, device=d).repeat(NT, 1).contiguous()
+                       for _ in range(2)]
+        self._arect_cur = 0
         # scene description
         self.scene_mesh, self.scene_offset = self._mesh_all[:N], self._off_all[:N]
         # internal buffers
@@ -138,6 +159,29 @@ class OcclusionEngine:
         self.scene_offset[idx] = torch.as_tensor(offsets, dtype=torch.float32).reshape(-1, 3, 3).to(self.device)
         self._put_mesh_rows(env_ids, m.numpy())
 
+    def _alpha_touch(self, rows) -> None:
+        """Rows of the alphas state were written as whole frames by something other than a tracked launch."""
+        self._arect[self._arect_cur][rows] = torch.tensor([0, 0, self.S - 1, self.S - 1], dtype=torch.int32, device=self.device)
+
+    def _ring_slot(self) -> dict:
+        """The output set of this step (output_ring >= 2): persistent obs / full_state holding background outside their rects."""
+        if self._ring is None:
+            d, S, NT = self.device, self.S, self.NT
+            f32 = dict(dtype=torch.float32, device=d)
+            self._ring = []
+            for _ in range(self.output_ring):
+                obs = torch.empty(NT, 4, S, S, **f32)
+                obs[:, :3] = 1.0
+                obs[:, 3] = -1.0   # white background, depth -1 (environment.py:378)
+                fs = torch.empty(NT, S, S, 4, **f32)
+                fs[..., :3] = 3.0
+                fs[..., 3] = 0.0   # environment.py:373 with all three alphas 0
+                rect = [torch.tensor([S, S, -1, -1], dtype=torch.int32, device=d).repeat(NT, 1).contiguous() for _ in range(2)]
+                self._ring.append(dict(obs=obs, fs=fs, rect=rect, cur=0))
+        slot = self._ring[self._ring_pos]
+        self._ring_pos = (self._ring_pos + 1) % self.output_ring
+        return slot
+
     # ---- workspace ------------------------------------------------------------------------
     def _scene_struct(self, n, scene_mesh, scene_offset, skip=None, pix_weight=None) -> nat.OccScene:
         pv, pf, vo, fo = self.pool.device_tensors()
@@ -147,6 +191,7 @@ class OcclusionEngine:
         sc.scene_mesh, sc.scene_offset = scene_mesh.data_ptr(), scene_offset.data_ptr()
         sc.n_meshes, sc.n_env, sc.img = len(self.pool), n, self.S
         sc.rec_cap = self._rec_cap()
+        sc.max_mesh_verts = self.pool.max_verts if self.setup_vertex_lds else 0
         atlas, aoff = self.pool.atlas_tensors()
         if atlas is not None:
             sc.pool_atlas, sc.mesh_atlas_off, sc.atlas_res = atlas.data_ptr(), aoff.data_ptr(), self.pool.atlas_res
@@ -274,8 +319,16 @@ class OcclusionEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _render(self, idx: Optional[torch.Tensor], cam_mode: int, cam_input: Optional[torch.Tensor], flags: int):
-        """Camera + render for all envs (idx None) or the compact subset idx.  Returns a dict of fresh tensors."""
+    def _camera_args(self, mode, action, el, az, rad, pos_out, n, pos2=None) -> nat.OccCameraArgs:
+        ca = nat.OccCameraArgs()
+        ca.mode, ca.n = mode, n
+        for name, t in (("action", action), ("el", el), ("az", az), ("radius", rad), ("cam_pos_out", pos_out), ("cam_pos_out2", pos2)):
+            setattr(ca, name, None if t is None else t.data_ptr())
+        return ca
+
+    def _render(self, idx: Optional[torch.Tensor], cam_mode: int, cam_input: Optional[torch.Tensor], flags: int, finish=None):
+        """Camera + render for all envs (idx None) or the compact subset idx, one occ_step call.  ``finish``: an
+        OccStepFinish whose reward bookkeeping the launch does as well.  Returns a dict of fresh tensors."""
         rows = self._mesh_host[: self.N] if idx is None else self._mesh_host[idx.cpu().numpy()]
         ws = self._ensure_workspace(self._records_needed(rows))
         d, S = self.device, self.S
@@ -296,10 +349,13 @@ class OcclusionEngine:
         cam_in = None if cam_input is None else cam_input.contiguous()
         # reset() leaves camera_position untouched (environment.py:302 zeros, never written by reset)
         write_pos = campos if cam_mode == nat.CAM_STEP else None
-        nat.check(self.lib.occ_camera(cam_mode, _p(cam_in), _p(el), _p(az), _p(rad), _p(cam), _p(write_pos), n, st),
-                  "occ_camera")
         out = {}
+        if cam_mode == nat.CAM_STEP:
+            out["pos"] = torch.empty(n, 3, **f32)  # this step's camera positions (info["position"] snapshot)
+        ca = self._camera_args(cam_mode, cam_in, el, az, rad, write_pos, n, out.get("pos"))
         ro = nat.OccRenderOut()
+        if finish is not None:
+            ro.finish = C.pointer(finish)
         if flags & nat.RENDER_HARD:
             out["obs"] = torch.empty(n, 4, S, S, **f32)
             ro.obs = out["obs"].data_ptr()
@@ -314,7 +370,7 @@ class OcclusionEngine:
         if self.pixel_weight is not None:
             pw = self.pixel_weight if idx is None else self.pixel_weight[idx].contiguous()
         sc = self._scene_struct(n, smesh, soff, pix_weight=pw)
-        nat.check(self.lib.occ_render(C.byref(sc), _p(cam), C.byref(ws), C.byref(ro), flags, self.K, st), "occ_render")
+        nat.check(self.lib.occ_step(C.byref(sc), C.byref(ca), _p(cam), C.byref(ws), C.byref(ro), flags, self.K, st), "occ_step")
         if idx is not None:
             if cam_mode == nat.CAM_STEP:
                 self.elevation[idx], self.azimuth[idx] = el, az
@@ -322,6 +378,9 @@ class OcclusionEngine:
             self.cam[idx] = cam
             if flags & nat.RENDER_SOFT:
                 self.alphas[idx] = alphas
+                self._alpha_touch(idx)
+        elif flags & nat.RENDER_SOFT:
+            self._alpha_touch(slice(0, n))  # an untracked launch wrote whole frames
         out["cam"] = cam
         out["_keep"] = (smesh, soff, el, az, rad, cam_in, pw)  # keep temporaries alive until the stream is done with them
         return out
@@ -368,7 +427,7 @@ class OcclusionEngine:
         S = self.S
         cam = torch.empty(m, nat.CAM_STRIDE, **f32)
         st = self._stream()
-        nat.check(self.lib.occ_camera(nat.CAM_LOOKAT, None, _p(el), _p(az), _p(rad), _p(cam), None, m, st), "occ_camera")
+        ca = self._camera_args(nat.CAM_LOOKAT, None, el, az, rad, None, m)
         out = dict(obs=torch.empty(m, 4, S, S, **f32), full_state=torch.empty(m, S, S, 4, **f32),
                    loss=torch.empty(m, **f32), alphas=torch.empty(m, 3, S, S, **f32), cam=cam,
                    radius=rad, azimuth=az, elevation=el, scene_mesh=smesh, scene_offset=soff, mesh_host=mesh_host)
@@ -376,8 +435,8 @@ class OcclusionEngine:
         ro.obs, ro.full_state, ro.loss, ro.alphas = (out["obs"].data_ptr(), out["full_state"].data_ptr(),
                                                      out["loss"].data_ptr(), out["alphas"].data_ptr())
         sc = self._scene_struct(m, smesh, soff)
-        nat.check(self.lib.occ_render(C.byref(sc), _p(cam), C.byref(ws), C.byref(ro), nat.RENDER_SOFT | nat.RENDER_HARD,
-                                      self.K, st), "occ_render")
+        nat.check(self.lib.occ_step(C.byref(sc), C.byref(ca), _p(cam), C.byref(ws), C.byref(ro), nat.RENDER_SOFT | nat.RENDER_HARD,
+                                    self.K, st), "occ_step")
         return out
 
     def commit_reset(self, env_ids, cand_ids, res) -> None:
@@ -394,6 +453,8 @@ class OcclusionEngine:
         self.camera_position[e] = 0.0
         self.cam[e] = res["cam"][c]
         self.alphas[e] = res["alphas"][c]
+        self._alpha_touch(e)
+        self.age[e] = 0
         loss = res["loss"][c]
         self.full_reward[e] = loss
         self.object_mass[e] = loss + 1.0
@@ -423,6 +484,7 @@ class OcclusionEngine:
         self._res_fs[sl] = res["full_state"][c]
         self._res_loss[sl] = res["loss"][c]
         self._alphas_all[self.N + sl] = res["alphas"][c]
+        self._alpha_touch(self.N + sl)
         self._cam_all[self.N + sl] = res["cam"][c]
 
     def refill_reserve(self, slots, mesh_ids, offsets) -> None:
@@ -458,7 +520,14 @@ class OcclusionEngine:
         Nothing here waits for the GPU; ``event.synchronize()`` before reading ``report_host``."""
         N, R, S = self.N, self.R, self.S
         term = torch.empty(R, 4, S, S, dtype=torch.float32, device=self.device)
+        reset_fs = torch.empty(R, S, S, 4, dtype=torch.float32, device=self.device)  # occlusion image of every slot taken now
         report = torch.empty(N + 2 * R + 2, dtype=torch.int32, device=self.device)
+        opts = nat.OccAutoResetOpts()
+        opts.age, opts.max_ep_len = self.age.data_ptr(), int(self.max_ep_len)
+        opts.reset_full_state = reset_fs.data_ptr()
+        opts.arect = self._arect[self._arect_cur].data_ptr()
+        if out.get("rect") is not None:
+            opts.rect = out["rect"].data_ptr()
         st = nat.OccEnvState()
         st.el, st.az, st.radius = self._el_all.data_ptr(), self._az_all.data_ptr(), self._rad_all.data_ptr()
         st.campos, st.cam, st.alphas = self.camera_position.data_ptr(), self._cam_all.data_ptr(), self._alphas_all.data_ptr()
@@ -469,14 +538,14 @@ class OcclusionEngine:
         store.skip = self._skip.data_ptr()
         nat.check(self.lib.occ_auto_reset(_p(out["done_u8"]), _p(out["loss_all"]), _p(self.status), N, R, _p(self.rs_state),
                                           _p(self.rs_tries), C.byref(st), _p(out["obs_all"]), _p(out["full_state_all"]),
-                                          C.byref(store), _p(term), S, _p(self._pairs), _p(report), self._stream()),
+                                          C.byref(store), _p(term), S, _p(self._pairs), _p(report), C.byref(opts), self._stream()),
                   "occ_auto_reset")
         self._rflip = getattr(self, "_rflip", 0) ^ 1
         host = self._report_host[self._rflip]
         host.copy_(report, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
-        return dict(report_host=host, event=ev, term=term, report=report)
+        return dict(report_host=host, event=ev, term=term, report=report, reset_fs=reset_fs)
 
     def step_flags(self, done_u8, loss_all) -> torch.Tensor:
         """(N + R + 1) int32 on the device: done | reserve scene accepted | any status bit (one D2H copy later)."""
@@ -502,17 +571,20 @@ class OcclusionEngine:
         reward = torch.empty(n, dtype=torch.float32, device=d)
         done = torch.empty(n, dtype=torch.uint8, device=d)
         grad_action = torch.empty(n, 2, dtype=torch.float32, device=d) if need_grad else None
+        # the reward bookkeeping (environment.py:381-392) rides on the launch that reduces the loss (OccStepFinish)
+        fr = self.full_reward if idx is None else self.full_reward[idx]
+        om = self.object_mass if idx is None else self.object_mass[idx]
+        fin = nat.OccStepFinish()
+        fin.full_reward, fin.object_mass, fin.reward, fin.done = fr.data_ptr(), om.data_ptr(), reward.data_ptr(), done.data_ptr()
+        fin.grad_action = None if grad_action is None else grad_action.data_ptr()
+        fin.n_step = n
         if with_reserve and idx is None and self.R > 0:
-            out = self._render_with_reserve(a, flags, pre_launch)
+            out = self._render_with_reserve(a, flags, pre_launch, fin)
         else:
             with_reserve = False
             if pre_launch is not None:
                 pre_launch()
-            out = self._render(idx, nat.CAM_STEP, a, flags)
-        fr = self.full_reward if idx is None else self.full_reward[idx]
-        om = self.object_mass if idx is None else self.object_mass[idx]
-        nat.check(self.lib.occ_step_finish(_p(out["loss"]), _p(out.get("grad_elaz")), _p(out["cam"]), _p(fr), _p(om),
-                                           _p(reward), _p(done), _p(grad_action), n, self._stream()), "occ_step_finish")
+            out = self._render(idx, nat.CAM_STEP, a, flags, fin)
         if idx is not None:
             self.full_reward[idx] = fr
         if need_grad:
@@ -522,17 +594,27 @@ class OcclusionEngine:
         out["done_u8"] = done
         return res + (out,) if with_reserve else res
 
-    def _render_with_reserve(self, actions, flags, pre_launch=None):
-        """One launch sequence over N stepping envs (OCC_CAM_STEP) + R reserve scenes (OCC_CAM_LOOKAT)."""
+    def _render_with_reserve(self, actions, flags, pre_launch=None, finish=None):
+        """One launch sequence (one occ_step call) over N stepping envs (OCC_CAM_STEP) + R reserve scenes (OCC_CAM_LOOKAT)."""
         d, S, N, NT = self.device, self.S, self.N, self.NT
         f32 = dict(dtype=torch.float32, device=d)
         st = self._stream()
-        obs = torch.empty(NT, 4, S, S, **f32)
-        fs = torch.empty(NT, S, S, 4, **f32)
-        loss = torch.empty(NT, **f32)
         ro = nat.OccRenderOut()
-        ro.obs, ro.full_state, ro.loss, ro.alphas = obs.data_ptr(), fs.data_ptr(), loss.data_ptr(), self._alphas_all.data_ptr()
         out = {}
+        if self.output_ring:
+            slot = self._ring_slot()
+            obs, fs = slot["obs"], slot["fs"]
+            rp, rn = slot["rect"][slot["cur"]], slot["rect"][slot["cur"] ^ 1]
+            slot["cur"] ^= 1
+            ro.rect_prev, ro.rect_next = rp.data_ptr(), rn.data_ptr()
+            out["rect"] = rn  # describes the set's content once this launch has run (auto-reset / fallback mark rows here)
+        else:
+            obs = torch.empty(NT, 4, S, S, **f32)
+            fs = torch.empty(NT, S, S, 4, **f32)
+        loss = torch.empty(NT, **f32)
+        ro.obs, ro.full_state, ro.loss, ro.alphas = obs.data_ptr(), fs.data_ptr(), loss.data_ptr(), self._alphas_all.data_ptr()
+        if finish is not None:
+            ro.finish = C.pointer(finish)
         if flags & nat.RENDER_GRAD:
             g = torch.empty(NT, 2, **f32)
             ro.grad_elaz = g.data_ptr()
@@ -541,29 +623,32 @@ class OcclusionEngine:
         if self.pixel_weight is not None:  # reserve rows (reset candidates) are scored unweighted
             pw = torch.ones(NT, S, S, **f32)
             pw[:N] = self.pixel_weight
-        cam_args = (nat.CAM_STEP, _p(actions), _p(self._el_all), _p(self._az_all), _p(self._rad_all), _p(self._cam_all),
-                    _p(self.camera_position), N, st)
+        out["pos"] = torch.empty(N, 3, **f32)  # this step's camera positions (info["position"] snapshot)
+        ca = self._camera_args(nat.CAM_STEP, actions, self._el_all, self._az_all, self._rad_all, self.camera_position, N, out["pos"])
         if pre_launch is not None:
             pre_launch()
         # pre_launch may have installed other scenes (auto-reset commits; the synchronous fallback reset may pick
         # larger models or grow the pool): size the record arrays and build the scene struct only now
         ws = self._ensure_workspace()
+        # the alphas state is persistent: tracked like a one-set ring (rows the launch skips keep their rect; the fallback
+        # reset above writes whole alpha frames and marks their rects in the CURRENT array: flip only now)
+        ro.arect_prev, ro.arect_next = self._arect[self._arect_cur].data_ptr(), self._arect[self._arect_cur ^ 1].data_ptr()
+        self._arect_cur ^= 1
         # the scene struct of the whole table only changes with the pool, the shader or the weights: kept between steps
-        key = (self.pool.version, int(self.shader), None if pw is None else pw.data_ptr(), self._rec_cap())
+        key = (self.pool.version, int(self.shader), None if pw is None else pw.data_ptr(), self._rec_cap(), self.setup_vertex_lds)
         if self._scene_cache is None or self._scene_cache[0] != key:
             self._scene_cache = (key, self._scene_struct(NT, self._mesh_all, self._off_all, self._skip, pix_weight=pw))
         sc = self._scene_cache[1]
-        nat.check(self.lib.occ_camera(*cam_args), "occ_camera")
         if not self._reserve_cam_done:  # reset() camera of the reserve rows: radius 4, az = el = 0, never changes
             nat.check(self.lib.occ_camera(nat.CAM_LOOKAT, None, _p(self._el_all[N:]), _p(self._az_all[N:]),
                                           _p(self._rad_all[N:]), _p(self._cam_all[N:]), None, self.R, st), "occ_camera")
             self._reserve_cam_done = True
         dump = os.environ.get("OCC_DEBUG_DUMP")
-        if dump:  # diagnostics: the inputs of the launch that is about to run (host sync)
+        if dump:  # diagnostics: the inputs of the launch that is about to run (host sync; cam / el / az as BEFORE this step's camera update)
             torch.save(dict(mesh=self._mesh_all.cpu(), off=self._off_all.cpu(), el=self._el_all.cpu(), az=self._az_all.cpu(),
                             rad=self._rad_all.cpu(), cam=self._cam_all.cpu(), actions=actions.cpu(), N=N, NT=NT), dump)
-        nat.check(self.lib.occ_render(C.byref(sc), _p(self._cam_all), C.byref(ws), C.byref(ro), flags, self.K, st),
-                  "occ_render")
+        nat.check(self.lib.occ_step(C.byref(sc), C.byref(ca), _p(self._cam_all), C.byref(ws), C.byref(ro), flags, self.K, st),
+                  "occ_step")
         out.update(obs=obs[:N], full_state=fs[:N], loss=loss[:N], cam=self._cam_all, obs_all=obs, loss_all=loss,
                    full_state_all=fs, _keep=pw)
         return out

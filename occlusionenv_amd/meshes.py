@@ -213,6 +213,7 @@ class MeshPool:
         self._keys: Dict[object, int] = {}
         self.version = 0
         self._max_faces = 0
+        self._max_verts = 0
         self._flushed = 0  # meshes already on the device
         self._sum_v = self._sum_f = self._sum_a = 0
         self._d_verts = _GrowBuf(self.device, torch.float32, (3,))
@@ -229,6 +230,10 @@ class MeshPool:
     @property
     def max_faces(self) -> int:
         return self._max_faces
+
+    @property
+    def max_verts(self) -> int:
+        return self._max_verts
 
     def num_faces(self, mesh_id: int) -> int:
         return int(self._faces[mesh_id].shape[0])
@@ -253,6 +258,7 @@ class MeshPool:
         self._faces.append(faces)
         self._atlas.append(atlas)
         self._max_faces = max(self._max_faces, int(faces.shape[0]))
+        self._max_verts = max(self._max_verts, int(verts.shape[0]))
         mid = len(self._verts) - 1
         if key is not None:
             self._keys[key] = mid

@@ -90,7 +90,11 @@ class BatchedPPO:
 
     def __init__(self, lr_actor: float = 3e-4, lr_critic: float = 1e-3, gamma: float = 0.99, K_epochs: int = 80,
                  eps_clip: float = 0.2, action_std_init: float = 0.6, device=None, seed: Optional[int] = None,
-                 graph_epochs: bool = True, fused: Optional[bool] = None):
+                 graph_epochs: bool = True, fused: Optional[bool] = None, encoder=None):
+        """``encoder``: any callable obs (N,4,S,S) -> features (N,256), run under no_grad - the socket for the frozen
+        encoder whose pooled features the reference stores (PPO.py:47,155-157: ``FullNetwork.forward``'s first output,
+        model.py:157-166).  Default: ``rollout.pooled_features`` (8x8 average pooling: the network is out of scope)."""
+        self.encoder = encoder
         self.gamma, self.eps_clip, self.K_epochs = gamma, eps_clip, K_epochs
         self.action_std = action_std_init
         if seed is not None:
@@ -125,7 +129,14 @@ class BatchedPPO:
     # ---- acting (PPO.py:152-164) ------------------------------------------------------------
     def select_action(self, obs: torch.Tensor, generator: Optional[torch.Generator] = None):
         """obs (N,4,S,S) -> (features, action, logprob) from the OLD policy."""
-        feats = rollout.pooled_features(obs)
+        if self.encoder is None:
+            feats = rollout.pooled_features(obs)
+        else:
+            with torch.no_grad():  # PPO.py:154: the encoder is frozen
+                feats = self.encoder(obs)
+            if feats.shape != (obs.shape[0], 256):
+                raise ValueError(f"the encoder must map (N,4,S,S) to (N,256) features, got {tuple(feats.shape)}")
+            feats = feats.detach().to(torch.float32).contiguous()
         action, logprob = self.policy_old.act(feats, generator)
         return feats, action, logprob
 
@@ -261,14 +272,33 @@ class BatchedPPO:
 
 
 def train_rollouts(venv, agent: BatchedPPO, n_updates: int = 1, T: int = 50, with_action_grad: bool = False,
-                   generator: Optional[torch.Generator] = None, on_step=None) -> list:
+                   generator: Optional[torch.Generator] = None, on_step=None, max_ep_len: Optional[int] = None,
+                   stagger: bool = True) -> list:
     """trainRL.py:189-229, batched: T vectorised steps (auto-reset inside the env) -> one PPO update; repeated.
     Returns the per-update stats (mean reward, loss before/after).  ``on_step(action, rewards)`` is called after every
-    step (and its backward): the hook of callers that consume ``action.grad`` (train_predict.py:52-58)."""
+    step (and its backward): the hook of callers that consume ``action.grad`` (train_predict.py:52-58).
+
+    ``max_ep_len`` (trainRL.py:22: 50): the reference ends every episode in ``env.reset()`` after max_ep_len steps,
+    done or not, and records ``is_terminal = done`` - False for such a reset, so the Monte-Carlo return of PPO.py:178-185
+    runs on across it.  Here the env counts every env's steps since its reset on the device and resets the expired ones
+    from its reserve (``SimpleVecEnv.max_ep_len``); ``stagger`` spreads the initial ages so that the envs, which all
+    start together, do not all expire in the same step (``SimpleVecEnv.stagger_ages``).
+
+    The per-step record exchange runs on a side stream (``rollout.RecordExchange``): the record of step t is stored
+    while step t + 1 renders."""
     obs = venv.reset()[:, 0]
+    if max_ep_len is not None:
+        venv.max_ep_len = int(max_ep_len)
+        if stagger:
+            venv.stagger_ages()
+    import torch.distributed as dist
+
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    xch = rollout.RecordExchange(obs.shape[0], obs.device, world, keep=True)
     stats = []
     for _ in range(n_updates):
         rew_sum = torch.zeros((), device=obs.device)
+        pending = False
         for _t in range(T):
             feats, action, logprob = agent.select_action(obs, generator)
             action = action.detach().requires_grad_(with_action_grad)
@@ -277,9 +307,13 @@ def train_rollouts(venv, agent: BatchedPPO, n_updates: int = 1, T: int = 50, wit
                 rewards.sum().backward()
             if on_step is not None:
                 on_step(action, rewards)
-            rec = rollout.pack_records(obs, action, logprob, rewards, dones, features=feats)  # PPO.py:158: the acting state's
-            agent.store(rollout.all_gather_records(rec))
+            if pending:
+                agent.store(xch.wait())  # the previous step's gathered records
+            xch.submit(obs, action, logprob, rewards, dones, features=feats)  # PPO.py:158: the acting state's features
+            venv.obs_consumer_event = xch.ready
+            pending = True
             rew_sum = rew_sum + rewards.detach().mean()
+        agent.store(xch.wait())
         st = agent.update()
         st["mean_reward"] = float(rew_sum) / T
         stats.append(st)

@@ -86,31 +86,40 @@ class RecordExchange:
     them in place (SimpleVecEnv's synchronous reset fallback writes into ``obs``) waits on it first.  On CPU tensors
     (gloo rehearsal, tests) the same sequence runs inline."""
 
-    def __init__(self, n_local: int, device, world: int):
+    def __init__(self, n_local: int, device, world: int, keep: bool = False):
+        """``keep``: every submit gathers into a tensor of its own (a learner stores the records of T steps:
+        ``ppo.train_rollouts``); otherwise one buffer is reused and ``wait()`` hands out the last step's view of it."""
         self.device = torch.device(device)
         self.world = int(world)
+        self.n_local = int(n_local)
+        self.keep = bool(keep)
         self.cuda = self.device.type == "cuda"
         self.side = torch.cuda.Stream(device=self.device) if (self.cuda and self.world > 1) else None
-        self.gathered = torch.empty(self.world * n_local, RECORD_FLOATS, device=self.device) if self.world > 1 else None
+        self.gathered = torch.empty(self.world * n_local, RECORD_FLOATS, device=self.device) if (self.world > 1 and not keep) else None
         self.ready = None
         self.last = None
 
-    def submit(self, obs, actions, logprob, rewards, dones) -> None:
+    def submit(self, obs, actions, logprob, rewards, dones, features=None) -> None:
+        """``features`` (n,256): the acting state's features when the caller has them (``pack_records``)."""
         rew, act = rewards.detach(), actions.detach()
+        dst = self.gathered
+        if self.keep and self.world > 1:  # allocated on the producing stream, filled on the side stream, read after wait()
+            dst = torch.empty(self.world * self.n_local, RECORD_FLOATS, device=self.device)
         if self.side is None:
-            rec = pack_records(obs, act, logprob, rew, dones)
-            self.last = all_gather_records(rec, self.gathered) if self.world > 1 else rec
+            rec = pack_records(obs, act, logprob, rew, dones, features=features)
+            self.last = all_gather_records(rec, dst) if self.world > 1 else rec
             return
         produced = torch.cuda.Event()
         produced.record(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.side):
             self.side.wait_event(produced)
-            rec = pack_records(obs, act, logprob, rew, dones)
+            rec = pack_records(obs, act, logprob, rew, dones, features=features)
             self.ready = torch.cuda.Event()
             self.ready.record(self.side)  # obs / actions / rewards / dones have been read
-            self.last = all_gather_records(rec, self.gathered)
-        for t in (obs, act, logprob, rew, dones):  # consumed on the side stream: keep their memory until it is done
-            t.record_stream(self.side)
+            self.last = all_gather_records(rec, dst)
+        for t in (obs, act, logprob, rew, dones, features, dst):  # used on the side stream: keep their memory until it is done
+            if t is not None:
+                t.record_stream(self.side)
 
     def wait(self) -> torch.Tensor:
         """The gathered (world * n, 261) records of the last submit, visible to the current stream."""

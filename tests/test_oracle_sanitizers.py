@@ -68,7 +68,7 @@ assert lib.occ_render(None, None, None, None, 3, 100, None) == 1
 assert lib.occ_step_finish(None, None, None, None, None, None, None, None, 4, None) == 1
 assert lib.occ_rasterize_meshes_naive(None, None, None, None, 1, 8, 8, 0.0, 1, 1, 0, 1, None, None, None, None, None) == 1
 assert lib.occ_sigmoid_alpha_blend_fwd(None, None, 4, 1, 1e-4, None, None) == 1
-assert lib.occ_auto_reset(None, None, None, 4, 2, None, None, None, None, None, None, None, 64, None, None, None) == 1
+assert lib.occ_auto_reset(None, None, None, 4, 2, None, None, None, None, None, None, None, 64, None, None, None, None) == 1
 assert lib.occ_reserve_refill(None, 3, 4, 2, None, None, None, None, None) == 1 and lib.occ_reserve_refill(None, 0, 4, 2, None, None, None, None, None) == 0
 print("ARG-OK")
 """ % ROOT
