@@ -318,7 +318,9 @@ int occ_sigmoid_alpha_blend_bwd(const float* dists, const int64_t* pix_to_face, 
  */
 #define OCC_PPO_FEATURES 256
 #define OCC_PPO_PARAMS (3 * OCC_PPO_FEATURES + 3)
+#ifndef OCC_PPO_MAX_BLOCKS
 #define OCC_PPO_MAX_BLOCKS 64
+#endif
 #define OCC_PPO_SCRATCH_FLOATS (OCC_PPO_MAX_BLOCKS * (OCC_PPO_PARAMS + 2))
 typedef struct OccPpoState {
     float *w_a, *b_a, *w_v, *b_v; /* action_head.weight (2,256), .bias (2), value_head.weight (1,256), .bias (1) */

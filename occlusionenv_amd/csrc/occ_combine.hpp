@@ -4,40 +4,86 @@
 // ------------------------------------------------------------------------------------------
 // combine kernel: one thread per pixel - occlusion image, loss / gradient partials, shading, outputs
 // ------------------------------------------------------------------------------------------
+// this step's footprint of env: the union of its object rects, in pixels (empty: x1 < x0)
+__device__ __forceinline__ int4 env_footprint(const OccWorkspace& ws, int env, int S) {
+    int ux0 = S, uy0 = S, ux1 = -1, uy1 = -1;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const int eo = env * 3 + o;
+        ciptr rect = as_const(ws.objrect + eo * 4);
+        if (as_const(ws.nrec + eo)[0] > 0 && rect[2] >= rect[0] && rect[3] >= rect[1]) {
+            ux0 = min(ux0, rect[0] * OCC_BLOCK);
+            uy0 = min(uy0, rect[1] * OCC_BLOCK);
+            ux1 = max(ux1, rect[2] * OCC_BLOCK + OCC_BLOCK - 1);
+            uy1 = max(uy1, rect[3] * OCC_BLOCK + OCC_BLOCK - 1);
+        }
+    }
+    return make_int4(ux0, uy0, ux1, uy1);
+}
+// the 256-pixel blocks of an S x S frame that meet pixel rows [y0, y1] (empty: first > last)
+__device__ __forceinline__ void rows_to_blocks(int y0, int y1, int S, int bpe, int& b0, int& b1) {
+    if (y1 < y0) { b0 = 1; b1 = 0; return; }
+    b0 = max((y0 * S) >> 8, 0);
+    b1 = min((y1 * S + S - 1) >> 8, bpe - 1);
+}
+
 template <bool SOFT, bool HARD, bool GRAD>
-__global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bpe) {
+__device__ __forceinline__ void combine_block(const RasterParams& P, int bpe, int env, int blk, float (*s_red)[3],
+                                              const int32_t* __restrict__ rprev, const int32_t* __restrict__ aprev);
+
+// Grid = n_env x G thread blocks; the blocks of an env share its 256-pixel blocks round robin.  With every written
+// output under REGION TRACKING (OccRenderOut.rect_prev / arect_prev: outside those rects the persistent outputs already
+// hold their background values) only the pixel blocks between the first and the last row that this step's footprint or
+// one of those rects touches are visited at all: a launch of one thread block per 256 pixels spent most of its time
+// starting 57 000 blocks that read six rects and exit (three quarters of a 128 x 128 frame are background).
+template <bool SOFT, bool HARD, bool GRAD>
+__global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bpe, int G) {
     __shared__ float s_red[4][3];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int env = blockIdx.x / bpe, blk = blockIdx.x - env * bpe;
+    const int tid = threadIdx.x;
+    const int env = blockIdx.x / G, g = blockIdx.x - env * G;
     const int S = P.sc.img;
-    // REGION TRACKING (OccRenderOut.rect_prev / arect_prev): outside those rects the persistent outputs already hold
-    // their background values, so only blocks that meet them or this step's object rects are written
     const int32_t* __restrict__ rprev = (HARD || SOFT) ? P.out.rect_prev : nullptr;
     const int32_t* __restrict__ aprev = SOFT ? P.out.arect_prev : nullptr;
     if (P.sc.skip && P.sc.skip[env]) {  // outputs of a skipped scene row stay untouched - and so do their rects
-        if (blk == 0 && tid < 4) {
+        if (g == 0 && tid < 4) {
             if (rprev && P.out.rect_next) P.out.rect_next[env * 4 + tid] = rprev[env * 4 + tid];
             if (aprev && P.out.arect_next) P.out.arect_next[env * 4 + tid] = aprev[env * 4 + tid];
         }
         return;
     }
-    if (blk == 0 && tid == 0 && (P.out.rect_next || P.out.arect_next)) {
-        // this step's footprint: the union of the object rects, in pixels (empty: x1 < x0)
-        int ux0 = S, uy0 = S, ux1 = -1, uy1 = -1;
-#pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            const int eo = env * 3 + o;
-            ciptr rect = as_const(P.ws.objrect + eo * 4);
-            if (as_const(P.ws.nrec + eo)[0] > 0 && rect[2] >= rect[0] && rect[3] >= rect[1]) {
-                ux0 = min(ux0, rect[0] * OCC_BLOCK);
-                uy0 = min(uy0, rect[1] * OCC_BLOCK);
-                ux1 = max(ux1, rect[2] * OCC_BLOCK + OCC_BLOCK - 1);
-                uy1 = max(uy1, rect[3] * OCC_BLOCK + OCC_BLOCK - 1);
-            }
-        }
-        if (P.out.rect_next) reinterpret_cast<int4*>(P.out.rect_next)[env] = make_int4(ux0, uy0, ux1, uy1);
-        if (P.out.arect_next) reinterpret_cast<int4*>(P.out.arect_next)[env] = make_int4(ux0, uy0, ux1, uy1);
+    const int4 fp = env_footprint(P.ws, env, S);
+    if (g == 0 && tid == 0) {
+        if (P.out.rect_next) reinterpret_cast<int4*>(P.out.rect_next)[env] = fp;
+        if (P.out.arect_next) reinterpret_cast<int4*>(P.out.arect_next)[env] = fp;
     }
+    // pixel blocks to visit: all of them unless every output this variant writes is tracked
+    int b0 = 0, b1 = bpe - 1;
+    const bool o_tracked = rprev != nullptr || !((HARD && P.out.obs) || (SOFT && P.out.full_state));
+    const bool a_tracked = aprev != nullptr || !(SOFT && P.out.alphas);
+    if (o_tracked && a_tracked) {
+        int y0 = fp.y, y1 = fp.w;
+        if (rprev) {
+            const int4 r = reinterpret_cast<const int4*>(rprev)[env];
+            if (r.z >= r.x && r.w >= r.y) { y0 = min(y0, r.y); y1 = max(y1, r.w); }
+        }
+        if (aprev) {
+            const int4 r = reinterpret_cast<const int4*>(aprev)[env];
+            if (r.z >= r.x && r.w >= r.y) { y0 = min(y0, r.y); y1 = max(y1, r.w); }
+        }
+        rows_to_blocks(y0, y1, S, bpe, b0, b1);
+    }
+    for (int blk = b0 + g; blk <= b1; blk += G) {
+        combine_block<SOFT, HARD, GRAD>(P, bpe, env, blk, s_red, rprev, aprev);
+        __syncthreads();  // s_red is reused by the next pixel block
+    }
+}
+
+template <bool SOFT, bool HARD, bool GRAD>
+__device__ __forceinline__ void combine_block(const RasterParams& P, int bpe, int env, int blk, float (*s_red)[3],
+                                              const int32_t* __restrict__ rprev, const int32_t* __restrict__ aprev) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int S = P.sc.img;
+    const int pidx = env * bpe + blk;  // this pixel block's slot in ws.partials
     const int pix = blk * 256 + tid;
     const bool live = pix < S * S;
     const int yi = live ? pix / S : 0, xi = live ? pix - (pix / S) * S : 0;
@@ -70,7 +116,7 @@ __global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bp
             };
             const bool wo = meets(rprev), wa = meets(aprev);
             if (SOFT) {
-                if (tid == 0) reinterpret_cast<float4*>(P.ws.partials)[blockIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (tid == 0) reinterpret_cast<float4*>(P.ws.partials)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (P.out.full_state && wo) reinterpret_cast<float4*>(P.out.full_state)[(size_t)env * S2 + pix] = make_float4(3.f, 3.f, 3.f, 0.f);
                 if (P.out.alphas && plane < 3 && wa)
                     reinterpret_cast<float4*>(P.out.alphas + ((size_t)env * 3 + plane) * S2 + p0)[quad] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -86,12 +132,14 @@ __global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bp
     float alpha[3] = {0.f, 0.f, 0.f}, dae[3] = {0.f, 0.f, 0.f}, daa[3] = {0.f, 0.f, 0.f};
     float hz = 3.0e38f;
     int hrec = -1, hobj = 0;
+    bool touched = false;  // the pixel lies in some object's rect of this step
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
         const int eo = env * 3 + o;
         ciptr rect = as_const(P.ws.objrect + eo * 4);
         const bool in = live && as_const(P.ws.nrec + eo)[0] > 0 && tx >= rect[0] && ty >= rect[1] && tx <= rect[2] &&
                         ty <= rect[3];
+        touched = touched || in;
         if (in) {
             const size_t opix = ((size_t)eo * S + yi) * S + xi;
             if (SOFT) {
@@ -113,6 +161,14 @@ __global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bp
         }
     }
     const size_t gp = (size_t)yi * S + xi;
+    // region tracking, per pixel: a tracked buffer already holds the background value at a pixel that lies neither in
+    // this step's object rects nor in the rect of what the buffer held before
+    auto in_prev = [&](const int32_t* __restrict__ rp) {
+        if (!rp) return true;
+        const int4 r = reinterpret_cast<const int4*>(rp)[env];
+        return xi >= r.x && xi <= r.z && yi >= r.y && yi <= r.w;
+    };
+    const bool wr_o = touched || in_prev(rprev), wr_a = touched || in_prev(aprev);
     if (SOFT) {
         // environment.py:373: image = i1*i2 + i2*i3 + i1*i3 ; RGB of every silhouette is 1
         const float I = alpha[0] * alpha[1] + alpha[1] * alpha[2] + alpha[0] * alpha[2];
@@ -143,12 +199,12 @@ __global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bp
                 b += s_red[w][1];
                 c += s_red[w][2];
             }
-            reinterpret_cast<float4*>(P.ws.partials)[blockIdx.x] = make_float4(a, b, c, 0.f);
+            reinterpret_cast<float4*>(P.ws.partials)[pidx] = make_float4(a, b, c, 0.f);
         }
         if (live) {
-            if (P.out.full_state)
+            if (P.out.full_state && wr_o)
                 reinterpret_cast<float4*>(P.out.full_state)[(size_t)env * S * S + gp] = make_float4(3.f, 3.f, 3.f, I);
-            if (P.out.alphas) {
+            if (P.out.alphas && wr_a) {
                 float* __restrict__ al = P.out.alphas + (size_t)env * 3 * S * S + gp;
                 al[0] = alpha[0];
                 al[(size_t)S * S] = alpha[1];
@@ -156,7 +212,7 @@ __global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bp
             }
         }
     }
-    if (HARD && live) {
+    if (HARD && live && wr_o) {
         // [P3D] HardFlatShader + hard_rgb_blend; depth in channel 3 (environment.py:378)
         float cr = 1.f, cg = 1.f, cb = 1.f, depth = -1.f;
         if (hrec >= 0) {
@@ -315,14 +371,21 @@ struct FinishArgs {  // OccStepFinish by value (n_step = 0: no fused tail)
     int n_step;
 };
 
+// Only the pixel blocks inside this step's footprint carry a partial (the combine kernel does not even visit the others
+// when its outputs are tracked; where it does, they hold exact zeros): lane l adds its blocks l, l + 64, ... of the
+// footprint in that order, which is the order - and the value - of the sum over all blocks.
 __global__ __launch_bounds__(64) void occ_reduce_kernel(const float* __restrict__ partials, int ntiles,
                                                         float* __restrict__ loss, float* __restrict__ grad_elaz,
-                                                        const int* __restrict__ skip, FinishArgs fin) {
+                                                        const int* __restrict__ skip, FinishArgs fin, OccWorkspace ws, int S) {
     const int env = blockIdx.x, lane = threadIdx.x;
     if (skip && skip[env]) return;
     const float4* __restrict__ p = reinterpret_cast<const float4*>(partials) + (size_t)env * ntiles;
     float l = 0.f, ge = 0.f, ga = 0.f;
-    for (int t = lane; t < ntiles; t += 64) {
+    const int4 fp = env_footprint(ws, env, S);
+    int tb0, tb1;
+    rows_to_blocks(fp.y, fp.w, S, ntiles, tb0, tb1);
+    for (int t = lane + (tb0 & ~63); t <= tb1; t += 64) {
+        if (t < tb0) continue;
         const float4 v = p[t];
         l += v.x;
         ge += v.y;

@@ -66,6 +66,11 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
 }
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
 __device__ __forceinline__ int wave_max_i(int v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, 64));

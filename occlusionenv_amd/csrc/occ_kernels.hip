@@ -153,6 +153,9 @@ extern "C" int occ_workspace_query(const OccScene* scene, int n_slots, OccWorksp
     out->nrec_bytes = N * 3 * sizeof(int32_t);
     out->objrect_bytes = N * 3 * 4 * sizeof(int32_t);
     out->queue_bytes = 8 * 16 * sizeof(uint32_t);  // eight queue heads, one 64-B line each
+#ifdef OCC_EXP_PARAM_PTR
+    out->queue_bytes += 1024;
+#endif
     out->lists_bytes = (size_t)n_slots * OCC_LOG_BYTES;  // per-wave K-buffer: the compacted candidate log
     const size_t S2 = (size_t)scene->img * scene->img;
     out->partials_bytes = N * ((S2 + 255) / 256) * 4 * sizeof(float);
@@ -262,11 +265,16 @@ extern "C" int occ_step(const OccScene* scene, const OccCameraArgs* camera, floa
     // world-space vertices of an object staged in LDS when they fit (OccScene.max_mesh_verts; 0 = gather from global memory)
     int vcap = scene->max_mesh_verts > 0 ? ((scene->max_mesh_verts + 63) & ~63) : 0;
     if (vcap > kSetupVcapMax) vcap = kSetupVcapMax;
+#ifdef OCC_EXP_SETUP_DUMMY_LDS  // occupancy experiment only: the LDS is reserved but the vertices are still gathered from memory
+    size_t vlds = (size_t)vcap * 3 * sizeof(float);
+    vcap = 0;
+#else
     const size_t vlds = (size_t)vcap * 3 * sizeof(float);
+#endif
     if (grad)
-        hipLaunchKernelGGL(occ_setup_kernel<true>, dim3(N * 3), dim3(256), vlds, st, *scene, cam, wsv, vcap);
+        hipLaunchKernelGGL((occ_setup_kernel<true, kSetupTB>), dim3(N * 3), dim3(kSetupTB), vlds, st, *scene, cam, wsv, vcap);
     else
-        hipLaunchKernelGGL(occ_setup_kernel<false>, dim3(N * 3), dim3(256), vlds, st, *scene, cam, wsv, vcap);
+        hipLaunchKernelGGL((occ_setup_kernel<false, kSetupTB>), dim3(N * 3), dim3(kSetupTB), vlds, st, *scene, cam, wsv, vcap);
     OCC_DBG_SYNC("setup");
     if (scene->rec_cap >= kSortMin) {
         // dense objects only: front-to-back scan order (LDS sort buffer: 8192 keys = 64 KiB)
@@ -302,17 +310,31 @@ extern "C" int occ_step(const OccScene* scene, const OccCameraArgs* camera, floa
     const bool prof = g_prof_on && g_prof_n < kProfMax;
     if (prof) (void)hipEventRecord(g_prof_ev[2 * g_prof_n], st);
     const int bpe = (scene->img * scene->img + 255) / 256;
-    const dim3 cgrid(N * bpe), cblock(256);
+    // thread blocks per env of the combine kernel: enough of them for a small launch, few enough that a big one does
+    // not start tens of thousands of blocks that find nothing to do (occ_combine_kernel)
+    int cG = bpe / 16 > (4096 + N - 1) / N ? bpe / 16 : (4096 + N - 1) / N;
+    if (cG > bpe) cG = bpe;
+    if (cG < 1) cG = 1;
+    const dim3 cgrid(N * cG), cblock(256);
+#ifdef OCC_EXP_PARAM_PTR  // experiment: the parameters travel through the tail of the queue buffer (needs queue_bytes + 1 KB)
+    static_assert(sizeof(RasterParams) <= 1024, "param slot");
+    if (hipMemcpyAsync(reinterpret_cast<char*>(ws->queue) + 512, &P, sizeof(P), hipMemcpyHostToDevice, st) != hipSuccess) return OCC_ERR_LAUNCH;
+#define OCC_RASTER_LAUNCH(SOFT_, HARD_, GRAD_)                                                                                \
+    hipLaunchKernelGGL((occ_raster2_kernel<SOFT_, HARD_, GRAD_>), grid, block, 0, st,                                         \
+                       (RasterParamsArg)(uintptr_t)(reinterpret_cast<char*>(ws->queue) + 512))
+#else
+#define OCC_RASTER_LAUNCH(SOFT_, HARD_, GRAD_) hipLaunchKernelGGL((occ_raster2_kernel<SOFT_, HARD_, GRAD_>), grid, block, 0, st, P)
+#endif
 #define OCC_LAUNCH(SOFT_, HARD_, GRAD_)                                                             \
     do {                                                                                            \
-        hipLaunchKernelGGL((occ_raster2_kernel<SOFT_, HARD_, GRAD_>), grid, block, 0, st, P);       \
+        OCC_RASTER_LAUNCH(SOFT_, HARD_, GRAD_);                                                     \
         OCC_DBG_SYNC("raster");                                                                     \
         if (prof) {                                                                                 \
             (void)hipEventRecord(g_prof_ev[2 * g_prof_n + 1], st);                                  \
             g_prof_nenv[g_prof_n] = N;                                                              \
             g_prof_n += 1;                                                                          \
         }                                                                                           \
-        hipLaunchKernelGGL((occ_combine_kernel<SOFT_, HARD_, GRAD_>), cgrid, cblock, 0, st, P, bpe); \
+        hipLaunchKernelGGL((occ_combine_kernel<SOFT_, HARD_, GRAD_>), cgrid, cblock, 0, st, P, bpe, cG); \
         OCC_DBG_SYNC("combine");                                                                    \
     } while (0)
     if (soft && hard && grad)
@@ -329,7 +351,7 @@ extern "C" int occ_step(const OccScene* scene, const OccCameraArgs* camera, floa
     if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
     if (soft && (out->loss || out->grad_elaz)) {
         hipLaunchKernelGGL(occ_reduce_kernel, dim3(N), dim3(64), 0, st, ws->partials, bpe, out->loss,
-                           grad ? out->grad_elaz : nullptr, scene->skip, fin);
+                           grad ? out->grad_elaz : nullptr, scene->skip, fin, wsv, scene->img);
         if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
     }
     return OCC_OK;

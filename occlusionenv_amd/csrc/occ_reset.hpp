@@ -110,7 +110,7 @@ struct StashArgs {
     OccReserveStore store;
     int img, n_env;
 };
-constexpr int kStashBlocks = 16;
+constexpr int kStashBlocks = 64;  // (16: one stash of ~14 slots took 14 us, four dependent load-store rounds per thread)
 __global__ __launch_bounds__(256) void occ_stash_kernel(StashArgs a) {
     const int r = blockIdx.x;
     if (a.rs_state[r] != OCC_RS_PENDING) return;
@@ -139,8 +139,8 @@ struct AutoCommitArgs {
 // grid.y = 1 (state) + obs_blocks + alpha_blocks: the copies are sized by the image - a block moves ~4 x 256 float4 per
 // plane it touches (with the 8 + 6 blocks that were enough at 128 x 128 the commit of ONE env took 40 us at 256 x 256,
 // 128 serial scalar iterations per thread in the alpha part)
-__host__ __device__ inline int commit_obs_blocks(int img) { return max(1, (img * img) / 1024); }
-__host__ __device__ inline int commit_alpha_blocks(int img) { return max(1, (3 * img * img) / 4096); }
+__host__ __device__ inline int commit_obs_blocks(int img) { return max(1, (img * img) / 256); }   // one float4 per thread and array
+__host__ __device__ inline int commit_alpha_blocks(int img) { return max(1, (3 * img * img) / 1024); }
 __global__ __launch_bounds__(256) void occ_auto_commit_kernel(AutoCommitArgs a) {
     const int k = blockIdx.x;
     if (k >= a.pairs[0]) return;

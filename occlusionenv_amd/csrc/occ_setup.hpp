@@ -191,11 +191,19 @@ __device__ __forceinline__ void write_record(float* __restrict__ r, uint4* __res
     *scan_row = make_uint4(t.bbox.x, t.bbox.y, t.bbox.z, (uint32_t)pos);
 }
 
+// Parts 0..4 of a record (positions, id, flags, 1 / area, float bbox, 1 / |edge|^2 x 3, specular term) and its bbox and
+// scan rows: write_record without the tangents.  The setup kernel stages a record in two pieces - these five parts,
+// then the three tangent parts - through a five-part LDS slot (see there).
+__device__ __forceinline__ void write_record_lo(float4* __restrict__ r4, uint4* __restrict__ bb, uint4* __restrict__ scan_row,
+                                                int pos, const Tri& t, int face_id, int flags, Shade sh) {
+    write_record<false>(reinterpret_cast<float*>(r4), bb, scan_row, pos, t, face_id, flags, sh);
+}
+
 // union pixel bbox and smallest depth key of every 64-entry chunk of the scan order (two-level scan)
 __device__ __forceinline__ void chunk_boxes(const uint4* __restrict__ scan, uint4* __restrict__ cbx, int nr, int wave,
-                                            int lane) {
+                                            int lane, int nwaves = 4) {
     const int nch = (nr + 63) >> 6;
-    for (int c = wave; c < nch; c += 4) {
+    for (int c = wave; c < nch; c += nwaves) {
         const int j = c * 64 + lane;
         uint4 bb = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
         if (j < nr) bb = scan[j];
@@ -220,7 +228,8 @@ struct RecSpan {
     int cap;      // records reserved
     size_t cbox;  // first chunk box
 };
-__device__ __forceinline__ RecSpan rec_span(const OccWorkspace& ws, int rec_cap, int eo) {
+template <class WS>  // (OccWorkspace in any address space)
+__device__ __forceinline__ RecSpan rec_span(const WS& ws, int rec_cap, int eo) {
     RecSpan r;
     if (ws.rec_off) {
         const long long b = ws.rec_off[eo];
@@ -461,19 +470,32 @@ __device__ __attribute__((noinline)) int clip_face_slow(const int* __restrict__ 
 // copies the object's WORLD-space vertices (pool vertex + offset, the very expression world_corner evaluates) into
 // dynamic LDS - coalesced - and the faces gather from there; an object with more than vcap vertices keeps the global
 // gathers (block-uniform choice).  Same values either way: the records do not change by a bit.
-template <bool GRAD>
-__global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const float* __restrict__ cam, OccWorkspace ws, int vcap) {
+#ifndef OCC_SETUP_TB
+#define OCC_SETUP_TB 512
+#endif
+constexpr int kSetupTB = OCC_SETUP_TB;  // threads per block of the setup kernel (one block per (env, object))
+constexpr int kHalfPad = 5;             // 16-byte parts of a staging slot: parts 0..4 of a record, then its three tangent parts (an odd
+                                        // stride: the lanes' 16-byte stores fall on different banks)
+// BLOCK SIZE AND LDS (round 4).  Sixteen waves per CU either way (<= 128 VGPRs); the block size decides how many waves
+// share ONE copy of the object's vertices.  Round 3: 256-thread blocks, four to a CU with 40 KB each - whole records
+// staged (9 KB per wave), no room for the vertices (31 KB for a 2 562-vertex mesh: with them only two blocks fitted and
+// the kernel got 18 % slower, although at EQUAL residency the LDS vertices beat the global gathers by 13 %).  Now a
+// record is staged in two pieces through a five-part slot (5 KB per wave), and two 512-thread blocks per CU hold their
+// vertices in 78 KB each.  Measured on one box (step minus raster, us; scripts/ab_toggle.py): 256 threads / global
+// gathers 800, 256 / LDS (two blocks per CU) 880, 512 / global 818, 512 / LDS 786, 1024 / global 914, 1024 / LDS 880.
+template <bool GRAD, int TB>
+__global__ __launch_bounds__(TB, 4) void occ_setup_kernel(OccScene sc, const float* __restrict__ cam, OccWorkspace ws, int vcap) {
+    constexpr int W = TB / 64;  // waves per block
     extern __shared__ float s_wv[];  // 3 x vcap floats: world x | y | z of the object's vertices
-    __shared__ int s_wcnt[2][4];  // double-buffered: one barrier per 256-face round
+    __shared__ int s_wcnt[2][W];  // double-buffered: one barrier per TB-face round
     __shared__ int s_rect[4];
-    __shared__ uint2 s_box[256];  // pixel bbox of this thread's face as its ONE visibility evaluation found it
-    __shared__ float4 s_rec[4 * 64 * kRecPad];  // per wave: the records of one round, staged for coalesced stores
+    __shared__ uint2 s_box[TB];  // pixel bbox of this thread's face as its ONE visibility evaluation found it
+    __shared__ float4 s_rec[W * 64 * kHalfPad];  // per wave: HALF the records of one round, staged for coalesced stores
     // work-item order (ws.order): faces per cell of a <= 16 x 16 grid over the image (cell = 8x8 tile, or a square of
     // tiles when the image has more than 16 tiles a side), faces too large to count cell by cell, tiles per cost class
     __shared__ uint32_t s_tcost[256];
     __shared__ uint32_t s_cls[kOrdClasses];
     __shared__ uint32_t s_big;
-    // (LDS stride 9 parts = 36 dwords: a 32-dword stride would put every lane's write on the same banks)
     const int eo = blockIdx.x;  // env*3 + object
     const int env = eo / 3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -500,7 +522,7 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
     const int nV = sc.mesh_vert_off[mesh + 1] - vo;
     const bool vlds = vcap > 0 && nV <= vcap;  // block-uniform
     if (vlds) {
-        for (int v = tid; v < nV; v += 256) {
+        for (int v = tid; v < nV; v += TB) {
             const float* pv = pool_verts + (size_t)(vo + v) * 3;
             s_wv[v] = pv[0] + ox;
             s_wv[vcap + v] = pv[1] + oy;
@@ -523,7 +545,7 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
     int cs = 0;  // tiles per cell side = 1 << cs
     while ((tiles_side >> cs) > 16) ++cs;
     if (ordered) {
-        s_tcost[tid] = 0u;
+        if (tid < 256) s_tcost[tid] = 0u;
         if (tid < kOrdClasses) s_cls[tid] = 0u;
         if (tid == 0) s_big = 0u;
     }
@@ -548,14 +570,14 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
         const int* pf = pool_faces + (size_t)(fo + tid) * 3;
         vi0 = pf[0]; vi1 = pf[1]; vi2 = pf[2];
     }
-    for (int base = 0; base < nF; base += 256, round ^= 1) {
+    for (int base = 0; base < nF; base += TB, round ^= 1) {
         const int f = base + tid;
         int cnt = 0;
         bool slow = false;
         float w0[3], w1[3], w2[3];  // world-space corners: all that a surviving face carries across the barrier
         const int c0 = vi0, c1 = vi1, c2 = vi2;
-        if (f + 256 < nF) {
-            const int* pf = pool_faces + (size_t)(fo + f + 256) * 3;
+        if (f + TB < nF) {
+            const int* pf = pool_faces + (size_t)(fo + f + TB) * 3;
             vi0 = pf[0]; vi1 = pf[1]; vi2 = pf[2];
         }
         if (f < nF) {
@@ -590,11 +612,22 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
         if (lane == 0) s_wcnt[round][wave] = __popcll(m1) + __popcll(m2);
         __syncthreads();
         int woff = 0, itot = 0;
+        if (W <= 4) {
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const int cw = s_wcnt[round][w];
-            if (w < wave) woff += cw;
-            itot += cw;
+            for (int w = 0; w < W; ++w) {
+                const int cw = s_wcnt[round][w];
+                if (w < wave) woff += cw;
+                itot += cw;
+            }
+        } else {  // sixteen counts held in sixteen registers cost the loop its register budget
+            int incl = lane < W ? s_wcnt[round][lane] : 0;  // inclusive scan over the first W lanes, read back as scalars
+#pragma unroll
+            for (int d = 1; d < W; d <<= 1) {
+                const int t = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += t;
+            }
+            itot = __builtin_amdgcn_readlane(incl, W - 1);
+            woff = wave ? __builtin_amdgcn_readlane(incl, __builtin_amdgcn_readfirstlane(wave) - 1) : 0;
         }
         const int pos = total + woff + pre;
         // Records of a wave are consecutive (ordered compaction): the survivors put theirs into LDS and the wave
@@ -603,6 +636,21 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
         // capacity limit, store directly.
         const int wstart = total + woff, nw = __popcll(m1) + __popcll(m2);
         const bool staged = (__ballot(slow) == 0ull) && (wstart + nw <= rec_cap);
+        bool rec_fast = false;  // this lane holds an unclipped survivor whose record goes through the wave's staging
+        // tangents of the three corners (parts 5..7): only for the faces that survived culling, vertex by vertex
+        auto tangents = [&](float4* __restrict__ r5) {
+            VVert q;
+            PVert pk;
+            view_from_world<true>(C, w0, q);
+            pk = project<true>(q);
+            r5[0] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
+            view_from_world<true>(C, w1, q);
+            pk = project<true>(q);
+            r5[1] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
+            view_from_world<true>(C, w2, q);
+            pk = project<true>(q);
+            r5[2] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
+        };
         if (cnt >= 1) {
             if (pos + cnt <= rec_cap) {
                 int x0, y0, x1, y1;
@@ -626,27 +674,13 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
                         tri.tx1 = (int)(bx.y & 0xFFFFu) / OCC_BLOCK;
                         tri.ty1 = (int)((bx.y >> 16) & 0x0FFFu) / OCC_BLOCK;
                     }
-                    auto emit = [&](float* __restrict__ r) {
-                        write_record<false>(r, bbs + pos, scan + pos, pos, tri, f, 0, sh);
-                        if (GRAD) {
-                            // tangents only for the faces that survived culling, stored vertex by vertex
-                            VVert q;
-                            PVert pk;
-                            view_from_world<true>(C, w0, q);
-                            pk = project<true>(q);
-                            reinterpret_cast<float4*>(r)[5] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
-                            view_from_world<true>(C, w1, q);
-                            pk = project<true>(q);
-                            reinterpret_cast<float4*>(r)[6] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
-                            view_from_world<true>(C, w2, q);
-                            pk = project<true>(q);
-                            reinterpret_cast<float4*>(r)[7] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
-                        }
-                    };
-                    if (staged) {
-                        emit(reinterpret_cast<float*>(&s_rec[(wave * 64 + pre) * kRecPad]));
+                    if (staged) {  // parts 0..4 now; the tangents follow once the wave has copied these out
+                        rec_fast = true;
+                        write_record_lo(&s_rec[(wave * 64 + pre) * kHalfPad], bbs + pos, scan + pos, pos, tri, f, 0, sh);
                     } else {
-                        emit(rec + (size_t)pos * OCC_REC_STRIDE);
+                        float4* __restrict__ r4 = reinterpret_cast<float4*>(rec + (size_t)pos * OCC_REC_STRIDE);
+                        write_record_lo(r4, bbs + pos, scan + pos, pos, tri, f, 0, sh);
+                        if (GRAD) tangents(r4 + 5);
                     }
                     x0 = tri.tx0; y0 = tri.ty0; x1 = tri.tx1; y1 = tri.ty1;
                 } else {
@@ -678,18 +712,28 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
                 overflow = true;
             }
         }
-        if (staged) {  // wave-uniform
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            constexpr int kP = GRAD ? kRecParts : 5;  // parts this variant writes
+        if (staged) {  // wave-uniform: parts 0..4 out, then the tangents (parts 5..7) through the same LDS slots
+            auto wave_sync = [] {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            };
             float4* __restrict__ dst = reinterpret_cast<float4*>(rec + (size_t)wstart * OCC_REC_STRIDE);
-            const float4* src = &s_rec[wave * 64 * kRecPad];
-            for (int i = lane; i < nw * kP; i += 64) {
-                const int rj = i / kP, part = i - rj * kP;
-                dst[rj * kRecParts + part] = src[rj * kRecPad + part];
+            const float4* src = &s_rec[wave * 64 * kHalfPad];
+            wave_sync();
+            for (int i = lane; i < nw * 5; i += 64) {
+                const int rj = i / 5, part = i - rj * 5;
+                dst[rj * kRecParts + part] = src[i];  // (slot stride = 5 parts: the staged parts are contiguous)
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            if (GRAD) {
+                wave_sync();
+                if (rec_fast) tangents(&s_rec[(wave * 64 + pre) * kHalfPad]);
+                wave_sync();
+                for (int i = lane; i < nw * 3; i += 64) {
+                    const int rj = i / 3, part = i - rj * 3;
+                    dst[rj * kRecParts + 5 + part] = src[rj * kHalfPad + part];
+                }
+            }
+            wave_sync();
         }
         total += itot;
     }
@@ -715,7 +759,7 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
         // pruning exact in ANY order; the order only decides how early it bites.
         const int nr = min(total, rec_cap);
         __syncthreads();  // scan[] of the whole object written (and s_rect complete)
-        chunk_boxes(scan, reinterpret_cast<uint4*>(ws.rec_cbox) + span.cbox, nr, wave, lane);
+        chunk_boxes(scan, reinterpret_cast<uint4*>(ws.rec_cbox) + span.cbox, nr, wave, lane, W);
     }
     if (ordered && total > 0 && total <= rec_cap && s_rect[2] >= s_rect[0] && s_rect[3] >= s_rect[1] && s_rect[0] >= 0 && s_rect[1] >= 0) {
         // every tile of the object's rect (= one work item of occ_raster2_kernel) gets its cost class and a rank
@@ -725,7 +769,7 @@ __global__ __launch_bounds__(256, 4) void occ_setup_kernel(OccScene sc, const fl
         const int tw = (s_rect[2] >> 1) - tx0 + 1, th = (s_rect[3] >> 1) - ty0 + 1;
         uint32_t* __restrict__ tord = ws.order + ord_tiles_word(sc.n_env) + (size_t)eo * tiles_side * tiles_side;
         const uint32_t big = s_big;
-        for (int local = tid; local < tw * th; local += 256) {
+        for (int local = tid; local < tw * th; local += TB) {
             const int tx = tx0 + local % tw, ty = ty0 + local / tw;
             const int cls = ord_class(s_tcost[min(ty >> cs, 15) * 16 + min(tx >> cs, 15)] + big);
             tord[local] = (atomicAdd(&s_cls[cls], 1u) << 5) | (uint32_t)cls;

@@ -77,7 +77,7 @@ class OcclusionEngine:
         self.output_ring = int(output_ring)
         self._ring, self._ring_pos = None, 0
         # the setup kernel stages every object's vertices in LDS once (False: three global gathers per face; same results)
-        self.setup_vertex_lds = True
+        self.setup_vertex_lds = bool(int(os.environ.get("OCC_SETUP_VERTEX_LDS", "1")))
         d = self.device
         f32 = dict(dtype=torch.float32, device=d)
         N = self.N

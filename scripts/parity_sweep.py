@@ -35,18 +35,7 @@ def stage_sweep(n, base):
 
     import collections
 
-    import numpy as np
-
-    from tests.parity_utils import alpha_of_records, explain_soft, make_case, run_engine
-
-    class _RecFaces:  # the engine's records in the shape explain_soft expects of the oracle's faces
-        def __init__(self, rec):
-            self.fv, self.c2u = rec["fv"].float().contiguous(), None
-            fl, idx = rec["flags"], np.arange(rec["fv"].shape[0])
-            nb = np.full(idx.shape[0], -1, dtype=np.int64)
-            nb[(fl & 1) != 0] = idx[(fl & 1) != 0] + 1
-            nb[(fl & 2) != 0] = idx[(fl & 2) != 0] - 1
-            self.nb = torch.from_numpy(nb)
+    from tests.parity_utils import RecordFaces as _RecFaces, alpha_of_records, explain_soft, make_case, run_engine
 
     reasons = collections.Counter()
     t0, tot_beyond, tot_pix, worst_rest, cases_beyond = time.time(), 0, 0, 0.0, 0
@@ -80,10 +69,17 @@ if __name__ == "__main__":
     if len(sys.argv) > 3 and sys.argv[3] == "stage":
         sys.exit(stage_sweep(n, base))
     wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
+    import collections
+
+    from tests import parity_utils as pu
+
+    pu.REASON_LOG = []  # (kind, object, y, x, reasons) of every pixel the classifier accepted
     worst, bad, ties, t0 = {}, 0, 0, time.time()
+    tot_pix = 0
     for seed in range(base, base + n):
         c = case_of_wide(seed) if wide else case_of(seed)
         res = run_parity_case(**c)
+        tot_pix += 2 * c["n_env"] * 3 * c["img"] * c["img"]  # reset render + step render, three objects
         v = violations(res)
         bad += 1 if v else 0
         ties += 1 if res["tie_pixels"] else 0
@@ -97,4 +93,14 @@ if __name__ == "__main__":
             + "; ".join(v)), flush=True)
     print("cases %d  violations %d  cases with tie pixels %d  %.0f s  worst: %s" % (
         n, bad, ties, time.time() - t0, " ".join("%s=%.2e" % kv for kv in sorted(worst.items()))))
+    # the exception rate: accepted pixels per acceptance rule (a pixel may carry several reasons; each is counted)
+    per_rule, per_kind = collections.Counter(), collections.Counter()
+    for kind, _o, _y, _x, reasons in pu.REASON_LOG:
+        per_kind[kind] += 1
+        for r in reasons:
+            per_rule[r] += 1
+    print("accepted pixels: %d of %d object-pixels (%.2e) by comparison: %s" % (
+        len(pu.REASON_LOG), tot_pix, len(pu.REASON_LOG) / max(tot_pix, 1), dict(per_kind)))
+    for r, n_r in per_rule.most_common():
+        print("  rule %-90s %6d pixels" % (r, n_r))
     sys.exit(1 if bad else 0)

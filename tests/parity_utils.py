@@ -329,6 +329,19 @@ def upstream_check(faces: _Faces, rec):
     return worst <= 1.0, worst, bounds
 
 
+class RecordFaces:
+    """The engine's own face records of one object (``snapshot_records``) in the shape ``explain_soft`` expects of the
+    oracle's face list: the tie classifier then runs on the geometry BOTH sides of a raster-stage comparison share."""
+
+    def __init__(self, rec):
+        self.fv, self.c2u = rec["fv"].float().contiguous(), None
+        fl, idx = rec["flags"], np.arange(rec["fv"].shape[0])
+        nb = np.full(idx.shape[0], -1, dtype=np.int64)
+        nb[(fl & 1) != 0] = idx[(fl & 1) != 0] + 1
+        nb[(fl & 2) != 0] = idx[(fl & 2) != 0] - 1
+        self.nb = torch.from_numpy(nb)
+
+
 def alpha_of_records(rec, S, K):
     """(2): the ORACLE's naive rasteriser + sigmoid blend on the engine's own records (identical geometry)."""
     from oracle import p3d_restate as O
@@ -602,15 +615,20 @@ def _oracle_grad64(case, i, img, radius, w, faces_per_pixel=100):
     return a.grad
 
 
+TIE_FRAC = 2e-4          # explained tie DECISIONS per env: at most this share of the object-pixels (floor 4)
+UPSTREAM_FRAC = 2e-3     # pixels accepted through the near / z-clipped rule per env: at most this share (floor 8)
+FOOTPRINT_FACTOR = 8     # tie PIXELS per env: at most this many per allowed decision (the blur footprint of a hair-flipped needle)
+
+
 def max_tie_pixels(img, n_objects=3):
     """Bound on explained tie decisions per env: near-ties are rounding coincidences, a handful per image."""
-    return max(4, int(2e-4 * img * img * n_objects))
+    return max(4, int(TIE_FRAC * img * img * n_objects))
 
 
 def max_upstream_pixels(img, n_objects=3):
     """Bound on the pixels accepted through the near / z-clipped rule per env (each passed the rule's three machine
     checks): with the camera inside an object a cut edge parallel to the clip plane moves along its whole length."""
-    return max(8, int(2e-3 * img * img * n_objects))
+    return max(8, int(UPSTREAM_FRAC * img * img * n_objects))
 
 
 def violations(res, tol=TOL):
@@ -622,7 +640,7 @@ def violations(res, tol=TOL):
         bad.append("too many tie pixels: %d (%d decisions)" % (res["tie_pixels"], res.get("tie_decisions", -1)))
     if res.get("upstream_pixels", 0) > max_upstream_pixels(res["img"]):
         bad.append("too many pixels under the near / z-clipped rule: %d" % res["upstream_pixels"])
-    if res["tie_pixels"] > 8 * max_tie_pixels(res["img"]) + max_upstream_pixels(res["img"]):  # footprints of hair-flipped needles included
+    if res["tie_pixels"] > FOOTPRINT_FACTOR * max_tie_pixels(res["img"]) + max_upstream_pixels(res["img"]):  # footprints of hair-flipped needles included
         bad.append("too many tie pixels: %d" % res["tie_pixels"])
     if not res.get("fs_arith", 0.0) < 1e-6:
         bad.append("fs_arith = %.3e" % res["fs_arith"])

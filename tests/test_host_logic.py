@@ -337,8 +337,22 @@ def test_tie_classifier_bands_are_frozen():
                   GRAD_NOISE_ULPS=256.0)
     for name, bound in frozen.items():
         assert 0 < getattr(pu, name) <= bound, (name, getattr(pu, name), bound)
+    # the per-env budgets of accepted pixels: tie decisions, pixels under the near / z-clipped rule, and the footprint
+    # allowance of hair-flipped needles (these three were still loose)
+    assert 0 < pu.TIE_FRAC <= 2e-4 and 0 < pu.UPSTREAM_FRAC <= 2e-3 and 0 < pu.FOOTPRINT_FACTOR <= 8
     for img in (64, 128, 256, 512):
         assert pu.max_tie_pixels(img) <= max(4, int(2e-4 * img * img * 3))
+        assert pu.max_upstream_pixels(img) <= max(8, int(2e-3 * img * img * 3))
+    # violations() applies exactly these budgets
+    res = dict(unexplained=[], tie_pixels=8 * pu.max_tie_pixels(64) + pu.max_upstream_pixels(64) + 1, tie_decisions=0, img=64,
+               upstream_pixels=0, fs_arith=0.0, grad_excess=0.0, grad_arbiter=[],
+               **{k: 0.0 for k in ("obs_maxabs", "obs0_maxabs", "alpha_maxabs", "alpha0_maxabs", "fs_maxabs", "render_maxabs",
+                                   "loss_rel", "loss0_rel", "reward_abs")})
+    assert any("too many tie pixels" in v for v in pu.violations(res))
+    res["tie_pixels"] -= 1
+    assert not pu.violations(res)
+    res["upstream_pixels"] = pu.max_upstream_pixels(64) + 1
+    assert any("near / z-clipped" in v for v in pu.violations(res))
 
 
 def test_hair_band_scales_with_the_perimeter_and_needle_depth_bound():

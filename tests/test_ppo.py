@@ -133,3 +133,41 @@ def test_closed_form_epoch_gradients_equal_autograd():
     assert torch.allclose(gm.sum(0), heads.action_head.bias.grad, rtol=1e-4, atol=1e-6)
     assert torch.allclose((gval[:, None] * feats).sum(0, keepdim=True), heads.value_head.weight.grad, rtol=1e-4, atol=1e-6)
     assert torch.allclose(gval.sum().reshape(1), heads.value_head.bias.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_encoder_hook_feeds_the_buffer():
+    """PPO.py:47,155-157: the buffer holds the FROZEN ENCODER's pooled features.  BatchedPPO(encoder=...) takes any
+    callable obs (N,4,S,S) -> (N,256); it runs under no_grad and its output is what select_action returns and acts on."""
+    calls = []
+    conv = torch.nn.Sequential(torch.nn.Conv2d(4, 16, 3, stride=2, padding=1), torch.nn.ReLU(), torch.nn.AdaptiveAvgPool2d(4),
+                               torch.nn.Flatten())  # (N, 16 * 4 * 4) = (N, 256)
+
+    def encoder(obs):
+        calls.append((tuple(obs.shape), torch.is_grad_enabled()))
+        return conv(obs)
+
+    agent = ppo.BatchedPPO(K_epochs=1, seed=0, fused=False, encoder=encoder)
+    obs = torch.rand(5, 4, 32, 32)
+    feats, action, logprob = agent.select_action(obs)
+    assert calls == [((5, 4, 32, 32), False)] and not feats.requires_grad
+    assert torch.allclose(feats, conv(obs).detach()) and feats.shape == (5, 256)
+    lp, _, _ = agent.policy_old.evaluate(feats, action)
+    assert torch.allclose(lp, logprob, atol=1e-6)
+    # default: the 8x8 pooling stand-in
+    f2, _, _ = ppo.BatchedPPO(K_epochs=1, seed=0, fused=False).select_action(obs)
+    assert torch.allclose(f2, rollout.pooled_features(obs))
+    import pytest
+
+    with pytest.raises(ValueError):
+        ppo.BatchedPPO(K_epochs=1, seed=0, fused=False, encoder=lambda o: torch.zeros(o.shape[0], 7)).select_action(obs)
+
+
+def test_returns_run_on_across_a_time_limit_reset():
+    """trainRL.py:191-229 resets the env after max_ep_len steps WITHOUT a terminal (is_terminal = done = False), so the
+    Monte-Carlo return of PPO.py:178-185 keeps flowing across that reset; a real terminal cuts it."""
+    rewards = torch.tensor([[1.0], [1.0], [1.0], [1.0]])
+    trunc = ppo.mc_returns(rewards, torch.zeros(4, 1, dtype=torch.bool), 0.5)           # time-limit reset after step 1: not a terminal
+    term = ppo.mc_returns(rewards, torch.tensor([[False], [True], [False], [False]]), 0.5)
+    assert trunc[:, 0].tolist() == [1.875, 1.75, 1.5, 1.0]
+    assert term[:, 0].tolist() == [1.5, 1.0, 1.5, 1.0]
+    assert trunc[:, 0].tolist() == _returns_reference_style([1.0] * 4, [False] * 4, 0.5)

@@ -129,3 +129,66 @@ def test_bench_step_sequence_world2_gloo():
         assert all(abs(a - b) < 1e-6 for ra, rb in zip(act, mine) for a, b in zip(ra, rb))
         for r in range(world):
             assert all(abs(g - 2 * a) < 1e-5 for rg, ra in zip(res[r][t][4], res[r][t][5]) for g, a in zip(rg, ra))
+
+
+class _StubResetVecEnv(_StubVecEnv):
+    """... plus reset() and the time-limit knobs train_rollouts touches."""
+
+    def __init__(self, lo, hi, img=16):
+        super().__init__(lo, hi, img)
+        self.max_ep_len, self.staggered = None, False
+
+    def reset(self):
+        ids = torch.arange(self.lo, self.lo + self.n, dtype=torch.float32)
+        return (ids[:, None, None, None, None] * torch.ones(self.n, 1, 4, self.img, self.img))
+
+    def stagger_ages(self, seed=None):
+        self.staggered = True
+
+
+def _ppo_rollout_worker(rank, world, port, n_total, T, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from occlusionenv_amd import ppo
+
+    lo, hi = rollout.env_shard(n_total, rank, world)
+    venv = _StubResetVecEnv(lo, hi)
+    agent = ppo.BatchedPPO(K_epochs=3, seed=0, fused=False)  # replicated learner: same seed on every rank
+    stored = []
+    orig_store = agent.store
+    agent.store = lambda rec: (stored.append(rec.clone()), orig_store(rec))[1]
+    stats = ppo.train_rollouts(venv, agent, n_updates=1, T=T, with_action_grad=True, generator=torch.Generator().manual_seed(3 + rank),
+                               max_ep_len=4)
+    q.put((rank, [r.tolist() for r in stored], {k: v.tolist() for k, v in agent.policy.state_dict().items()}, stats[0]["samples"],
+           venv.max_ep_len, venv.staggered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ppo_rollout_sequence_world2_gloo():
+    """ppo.train_rollouts (bench.py --workload ppo_rollout runs the same sequence): per step act -> env step -> backward ->
+    RecordExchange.submit (side-stream exchange on the GPU, inline here), the record of step t stored at step t + 1, the
+    last one before the update.  Both ranks must store the SAME T gathered tables in step order - every rank's rows in
+    global env order - and end up with identical heads (replicated learner, no gradient collective)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n_total, world, T = 6, 2, 5
+    procs = [ctx.Process(target=_ppo_rollout_worker, args=(r, world, port, n_total, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r[1:] for r in (q.get(timeout=180) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (rec0, heads0, n0, mel0, stag0), (rec1, heads1, n1, mel1, stag1) = res[0], res[1]
+    assert len(rec0) == T and n0 == n1 == T * n_total and mel0 == mel1 == 4 and stag0 and stag1
+    assert rec0 == rec1 and heads0 == heads1
+    for t, table in enumerate(rec0):
+        assert len(table) == n_total
+        for i, row in enumerate(table):
+            assert abs(row[259] - (row[256] ** 2 + row[257] ** 2 + i)) < 1e-4  # reward of global env i, its own action
+            assert row[260] == (1.0 if (i + t) % 3 == 0 else 0.0)            # done flag of step t: the tables are in step order
