@@ -281,6 +281,19 @@ class SimpleVecEnv(VecEnv):
         self._refill_reserve(empty)
         return []
 
+    def _drain_sync(self) -> bool:
+        """Wait for the last step's auto-reset report (the one host sync per batched step) and tell whether it needs the
+        host BEFORE the next launch: a finished env left without a reserve slot (synchronous fallback reset) or a status
+        bit.  Everything else the report says is bookkeeping that can follow the launch (``_drain``): the engine sizes
+        its record arrays for any commits it has not heard of (``_records_needed_all(ahead=True)``)."""
+        if self._pending is None:
+            return False
+        pend = self._pending[0]
+        pend["event"].synchronize()
+        rep = pend["report_host"].numpy()
+        N, R = self.num_envs, self.engine.R
+        return bool(rep[N + 2 * R] or rep[N + 2 * R + 1])
+
     def _drain_finish(self):
         """Second half of _drain: what the envs that took a reserve slot get from it.  Must run before the slots are
         refilled (``_rs_scene``) and before the launch after next (which may overwrite their stored renders)."""
@@ -312,9 +325,15 @@ class SimpleVecEnv(VecEnv):
             # the report of the previous step is read as late as possible: after this step's outputs are allocated
             # and its launch arguments are built, right before its first kernel launch
             empty = []
-            obs, rewards, dones, full_state, loss, out = eng.step(
-                actions, with_reserve=True, pre_launch=lambda: empty.extend(self._drain(defer_refill=True, finish=False)))
-            self._drain_finish()  # the rest of the previous step's report, now that this step is on its way
+
+            def pre_launch():  # the GPU idles from the report's arrival to this step's first launch: only what must precede it
+                if self._drain_sync():
+                    empty.extend(self._drain(defer_refill=True, finish=False))
+
+            obs, rewards, dones, full_state, loss, out = eng.step(actions, with_reserve=True, pre_launch=pre_launch)
+            # the rest of the previous step's report, now that this step is on its way
+            empty.extend(self._drain(defer_refill=True, finish=False))
+            self._drain_finish()
             # finished envs are reset ON THE DEVICE from the reserve (pairing + commit); the host reads the
             # report later (_drain).  NB out["obs_all"][:N] IS obs: the commit writes the reset observation in place
             eng.max_ep_len = int(self.max_ep_len or 0)

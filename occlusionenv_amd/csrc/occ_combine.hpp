@@ -151,10 +151,13 @@ __device__ __forceinline__ void combine_block(const RasterParams& P, int bpe, in
                 }
             }
             if (HARD) {
+                // (the record index is fetched WITH the depth, not after the comparison: the kernel lives on memory latency,
+                // and a load that waits for another load's result is a round trip more per object)
                 const float z = P.ws.obj_hz[opix];
+                const int hr = P.ws.obj_hrec[opix];
                 if (z < hz) {  // strict: on equal depth the earlier object of the joined scene wins
                     hz = z;
-                    hrec = P.ws.obj_hrec[opix];
+                    hrec = hr;
                     hobj = o;
                 }
             }

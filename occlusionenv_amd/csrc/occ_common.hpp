@@ -61,6 +61,15 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() also waits for every outstanding global store of the
+// wave (s_waitcnt vmcnt(0)): in a loop that streams records out and hands small things over through LDS, each barrier
+// then costs a store round trip to memory.  Use where nothing that crosses the barrier went through global memory.
+__device__ __forceinline__ void block_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);

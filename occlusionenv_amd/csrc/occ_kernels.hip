@@ -153,9 +153,6 @@ extern "C" int occ_workspace_query(const OccScene* scene, int n_slots, OccWorksp
     out->nrec_bytes = N * 3 * sizeof(int32_t);
     out->objrect_bytes = N * 3 * 4 * sizeof(int32_t);
     out->queue_bytes = 8 * 16 * sizeof(uint32_t);  // eight queue heads, one 64-B line each
-#ifdef OCC_EXP_PARAM_PTR
-    out->queue_bytes += 1024;
-#endif
     out->lists_bytes = (size_t)n_slots * OCC_LOG_BYTES;  // per-wave K-buffer: the compacted candidate log
     const size_t S2 = (size_t)scene->img * scene->img;
     out->partials_bytes = N * ((S2 + 255) / 256) * 4 * sizeof(float);
@@ -316,18 +313,9 @@ extern "C" int occ_step(const OccScene* scene, const OccCameraArgs* camera, floa
     if (cG > bpe) cG = bpe;
     if (cG < 1) cG = 1;
     const dim3 cgrid(N * cG), cblock(256);
-#ifdef OCC_EXP_PARAM_PTR  // experiment: the parameters travel through the tail of the queue buffer (needs queue_bytes + 1 KB)
-    static_assert(sizeof(RasterParams) <= 1024, "param slot");
-    if (hipMemcpyAsync(reinterpret_cast<char*>(ws->queue) + 512, &P, sizeof(P), hipMemcpyHostToDevice, st) != hipSuccess) return OCC_ERR_LAUNCH;
-#define OCC_RASTER_LAUNCH(SOFT_, HARD_, GRAD_)                                                                                \
-    hipLaunchKernelGGL((occ_raster2_kernel<SOFT_, HARD_, GRAD_>), grid, block, 0, st,                                         \
-                       (RasterParamsArg)(uintptr_t)(reinterpret_cast<char*>(ws->queue) + 512))
-#else
-#define OCC_RASTER_LAUNCH(SOFT_, HARD_, GRAD_) hipLaunchKernelGGL((occ_raster2_kernel<SOFT_, HARD_, GRAD_>), grid, block, 0, st, P)
-#endif
 #define OCC_LAUNCH(SOFT_, HARD_, GRAD_)                                                             \
     do {                                                                                            \
-        OCC_RASTER_LAUNCH(SOFT_, HARD_, GRAD_);                                                     \
+        hipLaunchKernelGGL((occ_raster2_kernel<SOFT_, HARD_, GRAD_>), grid, block, 0, st, P);       \
         OCC_DBG_SYNC("raster");                                                                     \
         if (prof) {                                                                                 \
             (void)hipEventRecord(g_prof_ev[2 * g_prof_n + 1], st);                                  \

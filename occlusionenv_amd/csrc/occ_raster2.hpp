@@ -146,17 +146,11 @@ __device__ unsigned long long g_dbg_time[112];
 #define OCC_RASTER2_WAVES_PER_SIMD 3
 #endif
 
-#ifdef OCC_EXP_PARAM_PTR  // experiment: the launch parameters behind a pointer, s_load-ed where they are used
-typedef const __attribute__((address_space(4))) RasterParams* RasterParamsArg;
-#define OCC_RASTER_PARAMS_DECL RasterParamsArg Pc
-#define OCC_RASTER_PARAMS_BIND const __attribute__((address_space(4))) RasterParams& P = *Pc
-#else
-#define OCC_RASTER_PARAMS_DECL RasterParams P
-#define OCC_RASTER_PARAMS_BIND do { } while (0)
-#endif
+// (Launch parameters behind a constant-address-space pointer instead of by value - so that they are s_load-ed where
+// they are used rather than kept or spilled - were measured in round 4: SGPR spills 83 -> 58, kernel 1.949 -> 1.941 ms,
+// inside the noise; none of the spill code sits in the round loop.  Not kept.)
 template <bool SOFT, bool HARD, bool GRAD>
-__global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_kernel(OCC_RASTER_PARAMS_DECL) {
-    OCC_RASTER_PARAMS_BIND;
+__global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_kernel(RasterParams P) {
     const int lane = threadIdx.x;
     const int S = P.sc.img;
     const float fS = (float)S;

@@ -610,7 +610,12 @@ __global__ __launch_bounds__(TB, 4) void occ_setup_kernel(OccScene sc, const flo
         const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
         const int pre = __popcll(m1 & lt) + __popcll(m2 & lt);
         if (lane == 0) s_wcnt[round][wave] = __popcll(m1) + __popcll(m2);
+#ifdef OCC_SETUP_FULL_BARRIER  // (A/B build)
         __syncthreads();
+#else
+        // (only the wave counts cross this barrier, through LDS: no need to wait for the round's record stores to land)
+        block_lds_barrier();
+#endif
         int woff = 0, itot = 0;
         if (W <= 4) {
 #pragma unroll

@@ -120,6 +120,7 @@ class OcclusionEngine:
         self._rec_total = 0
         self._mesh_host = np.zeros((NT, 3), dtype=np.int64)  # host copy of _mesh_all (kept current before every launch)
         self._need_all = None        # cached _records_needed(_mesh_host) (see _put_mesh_rows)
+        self._need_res = 0           # ... of the reserve rows alone
         self._scene_cache = None     # (key, OccScene) of the last whole-table scene struct
         self._faces_np = np.zeros(0, dtype=np.int64)
         self._faces_ver = -1
@@ -215,15 +216,22 @@ class OcclusionEngine:
                 and np.unique(rows).size == rows.size:
             f_old = self._faces_np[self._mesh_host[rows].reshape(-1)]
             f_new = self._faces_np[m.reshape(-1)]
-            self._need_all += int((((2 * f_new + 63) >> 6) << 6).sum() - (((2 * f_old + 63) >> 6) << 6).sum())
+            d = ((((2 * f_new + 63) >> 6) << 6) - (((2 * f_old + 63) >> 6) << 6)).reshape(-1, 3).sum(1)
+            self._need_all += int(d.sum())
+            self._need_res += int(d[rows >= self.N].sum())
         else:
             self._need_all = None  # recomputed on demand
         self._mesh_host[rows] = m
 
-    def _records_needed_all(self) -> int:
+    def _records_needed_all(self, ahead: bool = False) -> int:
+        """Records the whole table (envs + reserve rows) needs.  ``ahead``: an upper bound that also holds if the DEVICE
+        has meanwhile installed reserve scenes in env rows that the host has not heard of yet (auto-reset commits of the
+        last step, report not processed): every such commit replaces an env's scene by a slot's, so counting the
+        reserve rows twice covers any number of them."""
         if self._need_all is None or self._faces_ver != self.pool.version:
             self._need_all = self._records_needed(self._mesh_host)
-        return self._need_all
+            self._need_res = self._records_needed(self._mesh_host[self.N:]) if self.R else 0
+        return self._need_all + (self._need_res if ahead else 0)
 
     def _rec_cap(self) -> int:
         # a z-clipped face can split in two (SURVEY A.3): worst case 2 records per face
@@ -629,7 +637,7 @@ class OcclusionEngine:
             pre_launch()
         # pre_launch may have installed other scenes (auto-reset commits; the synchronous fallback reset may pick
         # larger models or grow the pool): size the record arrays and build the scene struct only now
-        ws = self._ensure_workspace()
+        ws = self._ensure_workspace(self._records_needed_all(ahead=True))
         # the alphas state is persistent: tracked like a one-set ring (rows the launch skips keep their rect; the fallback
         # reset above writes whole alpha frames and marks their rects in the CURRENT array: flip only now)
         ro.arect_prev, ro.arect_next = self._arect[self._arect_cur].data_ptr(), self._arect[self._arect_cur ^ 1].data_ptr()
