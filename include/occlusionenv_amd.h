@@ -319,7 +319,7 @@ int occ_sigmoid_alpha_blend_bwd(const float* dists, const int64_t* pix_to_face, 
 #define OCC_PPO_FEATURES 256
 #define OCC_PPO_PARAMS (3 * OCC_PPO_FEATURES + 3)
 #ifndef OCC_PPO_MAX_BLOCKS
-#define OCC_PPO_MAX_BLOCKS 64
+#define OCC_PPO_MAX_BLOCKS 128
 #endif
 #define OCC_PPO_SCRATCH_FLOATS (OCC_PPO_MAX_BLOCKS * (OCC_PPO_PARAMS + 2))
 typedef struct OccPpoState {

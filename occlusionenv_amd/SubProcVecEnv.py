@@ -129,9 +129,12 @@ class SimpleVecEnv(VecEnv):
         dev = torch.device(f"cuda:{torch.cuda.current_device()}") if torch.cuda.is_available() else env.device
         # reserve slots: speculative auto-reset scenes rendered inside every batched step (see engine.py)
         same_data = all(e.shapenet_dataset is env.shapenet_dataset for e in self.envs)
-        # ~0.8 % of the envs finish per step and ~58 % of the candidates pass; only slots under test are rendered, so
-        # a generous N/8 slots cost next to nothing and keep the reserve far from running dry
-        reserve = min(512, max(self.num_envs // 8, 2 if self.num_envs >= 16 else 0)) if same_data else 0
+        # ~0.8 % of the envs finish per step and ~58 % of the candidates pass; with the reference's episode time limit
+        # (max_ep_len = 50, trainRL.py:22) another 2 % expire per step, and a slot takes three to four steps from taken
+        # to READY again.  Only slots under test are rendered, so generous N/4 slots cost next to nothing and keep the
+        # reserve from running dry (with N/8 the time-limited PPO rollout fell back to reading the report at the end of
+        # most steps: 3.31 instead of 2.87 ms per step at 256 envs)
+        reserve = min(512, self.num_envs // 4) if (same_data and self.num_envs >= 16) else 0
         self.engine = OcclusionEngine(shared_pool(dev), self.num_envs, env.img_size, device=dev, reserve=reserve)
         self._age_host = np.zeros(self.num_envs, dtype=np.int64)  # the time limit's counters of the host-driven path (no reserve)
         self.max_ep_len = None

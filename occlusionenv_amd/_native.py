@@ -142,7 +142,7 @@ class OccPpoState(C.Structure):
 
 PPO_FEATURES = 256
 PPO_PARAMS = 3 * PPO_FEATURES + 3
-PPO_SCRATCH_FLOATS = 64 * (PPO_PARAMS + 2)
+PPO_SCRATCH_FLOATS = 128 * (PPO_PARAMS + 2)
 
 
 class OccReserveStore(C.Structure):

@@ -75,6 +75,39 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
 }
+// Sum over the 64 lanes with DPP row operations (VALU, a few cycles each) instead of six ds_bpermute round trips through
+// the LDS crossbar (~100 cycles each, and dependent on one another): quad swaps, half-row and row mirrors give every lane
+// its 16-lane row's sum, row_bcast:15 / row_bcast:31 fold the four rows into lane 63, whose value every lane returns.
+// (A fixed summation order, different from the xor butterfly's.)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    auto dpp = [](float x, auto ctrl, auto row_mask) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(row_mask)::value, 0xF, true));
+    };
+    using std::integral_constant;
+    v += dpp(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xF>{});   // quad_perm [1,0,3,2]
+    v += dpp(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xF>{});   // quad_perm [2,3,0,1]
+    v += dpp(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xF>{});  // row_half_mirror
+    v += dpp(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xF>{});  // row_mirror
+    v += dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xA>{});  // row_bcast:15 into rows 1 and 3
+    v += dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xC>{});  // row_bcast:31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// Unsigned minimum / maximum over the 64 lanes the same way (lanes a DPP step does not reach keep the identity).
+template <bool MAX>
+__device__ __forceinline__ uint32_t wave_minmax_u32_dpp(uint32_t v) {
+    auto step = [](uint32_t x, auto ctrl, auto row_mask) {
+        const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(MAX ? 0 : -1 /* the identity: 0 / 0xFFFFFFFF */, (int)x, decltype(ctrl)::value, decltype(row_mask)::value, 0xF, false);
+        return MAX ? max(x, o) : min(x, o);
+    };
+    using std::integral_constant;
+    v = step(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xF>{});
+    v = step(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xF>{});
+    v = step(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xF>{});
+    v = step(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xF>{});
+    v = step(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xA>{});
+    v = step(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xC>{});
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);

@@ -457,9 +457,13 @@ extern "C" int occ_ppo_update(const float* feats, const float* actions, const fl
     A.w_a = state->w_a; A.b_a = state->b_a; A.w_v = state->w_v; A.b_v = state->b_v;
     A.m = state->adam_m; A.v = state->adam_v; A.step = state->adam_step;
     A.partials = scratch; A.counter = counter;
-    // a wave takes ~12 samples of a 10^4-sample rollout: 64 blocks of 16 waves; few rows for the last block's sum
+    // A wave takes ~12 samples of a 10^4-sample rollout: 64 blocks of 16 waves, few rows for the last block's sum.  The
+    // replicated learner of an 8-GPU node sees 8 x the samples: from 2^16 samples on, twice the blocks (measured, us per
+    // epoch at 12 800 / 51 200 / 102 400 samples: 64 blocks 40 / 67 / 106, 128 blocks 49 / 69 / 88, 256 blocks 50 / 103 / 115:
+    // more rows cost the last block more than the extra waves save until the sample loop dominates).
+    const long long cap = M >= 65536 ? OCC_PPO_MAX_BLOCKS : (OCC_PPO_MAX_BLOCKS < 64 ? OCC_PPO_MAX_BLOCKS : 64);
     const long long want = (M + 16 * 8 - 1) / (16 * 8);
-    const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > OCC_PPO_MAX_BLOCKS ? OCC_PPO_MAX_BLOCKS : want));
+    const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > cap ? cap : want));
     for (int e = 0; e < n_epochs; ++e) {
         A.losses = losses + 2 * e;
         hipLaunchKernelGGL(occ_ppo_epoch_kernel, dim3(blocks), dim3(kPpoThreads), 0, (hipStream_t)stream, A);

@@ -320,9 +320,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             uint32_t L = kmin_tile > 4096u ? kmin_tile - 4096u : 0u;
             int need = K, sh = 0;
             {
-                uint32_t kmx = kmx_lane;  // largest key in the log: wave maximum of the lanes' own
-#pragma unroll
-                for (int mm = 32; mm >= 1; mm >>= 1) kmx = max(kmx, (uint32_t)__shfl_xor((int)kmx, mm, 64));
+                const uint32_t kmx = wave_minmax_u32_dpp<true>(kmx_lane);  // largest key in the log: wave maximum of the lanes' own
                 const uint32_t range = kmx >= L ? kmx - L : 0u;
                 sh = range ? max(0, (32 - __builtin_clz(range)) - kSelBits) : 0;
             }
@@ -575,10 +573,8 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 uint4 cb = kEmptyBox;
                 if (cwin + lane < nch) cb = cbx[cwin + lane];
                 const bool hit = touches(cb);
-                uint32_t km = hit ? cb.z : 0xFFFFFFFFu;
-#pragma unroll
-                for (int mm = 32; mm >= 1; mm >>= 1) km = min(km, (uint32_t)__shfl_xor((int)km, mm, 64));
-                kmin_tile = min(kmin_tile, (uint32_t)__builtin_amdgcn_readfirstlane((int)km));
+                // (DPP reductions, not xor butterflies through the LDS crossbar: six dependent ds_bpermute round trips each)
+                kmin_tile = min(kmin_tile, wave_minmax_u32_dpp<false>(hit ? cb.z : 0xFFFFFFFFu));
                 cmask = __ballot(hit && cb.z < thrB);
             }
             const int bit = __builtin_ctzll(cmask);
@@ -923,9 +919,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     const uint32_t hk = (uint32_t)(s_hard[lane] >> 32);  // 0xFFFFFFFF while the pixel has no face
                     bound = SOFT ? max(bound, hk) : hk;
                 }
-#pragma unroll
-                for (int mm = 32; mm >= 1; mm >>= 1) bound = max(bound, (uint32_t)__shfl_xor((int)bound, mm, 64));
-                thrB = (uint32_t)__builtin_amdgcn_readfirstlane((int)bound);
+                thrB = wave_minmax_u32_dpp<true>(bound);
             }
             OCC_T(6);  // pruning bounds
             fseq_base += nst;

@@ -121,7 +121,7 @@ def test_auto_reset_on_done(ds):
 
 
 def test_auto_reset_from_the_speculative_reserve(ds):
-    """N = 16 -> 2 reserve scenes ride along with every step; a finished env takes one without an extra render.
+    """N = 16 -> 4 reserve scenes ride along with every step; a finished env takes one without an extra render.
     The installed state must be exactly what a synchronous reset() of that scene computes."""
     from occlusionenv_amd.engine import OcclusionEngine
     from environment import OcclusionEnv
@@ -133,15 +133,15 @@ def test_auto_reset_from_the_speculative_reserve(ds):
     venv._reset_envs(list(range(N)), torch.zeros(N))  # reset() itself draws unseeded azimuths (SubProcVecEnv.py:233)
     venv._warm_reserve()
     eng = venv.engine
-    assert eng.R == 2 and bool((venv._rs_state == 2).all()) and eng.rs_state.tolist() == [2, 2]
+    assert eng.R == 4 and bool((venv._rs_state == 2).all()) and eng.rs_state.tolist() == [2, 2, 2, 2]
     off = eng.scene_offset[5].clone()
     off[1, 0], off[2, 0] = 50.0, -50.0  # no occlusion left -> env 5 finishes
     eng.scene_offset[5] = off
-    ready_scenes = [venv._rs_scene[r] for r in range(2)]
+    ready_scenes = [venv._rs_scene[r] for r in range(4)]
     # zero actions leave every camera where it is (environment.py:358): only env 5 can finish
     obs, rewards, dones, infos = venv.step(torch.zeros(N, 2, device="cuda"))
     assert bool(dones[5]) and "terminal_observation" in infos[5]
-    assert int(dones.sum()) <= 2, "at most the two reserve slots are needed"
+    assert int(dones.sum()) <= 4, "at most the four reserve slots are needed"
     assert venv.envs[5]._scene in ready_scenes  # taken from the reserve
     ids, offs = venv.envs[5]._scene
     ref = eng.evaluate_scenes([ids], [offs], 4.0, 0.0, 0.0)
@@ -157,7 +157,7 @@ def test_auto_reset_from_the_speculative_reserve(ds):
 
 def test_auto_reset_deferred_report_and_dry_reserve(ds):
     """The auto-reset runs on the device; the host reads its report at the NEXT step (or when infos are read).
-    Three envs finish at once with two reserve slots: two are reset from the reserve by the device, the third by
+    Five envs finish at once with four reserve slots: four are reset from the reserve by the device, the fifth by
     the synchronous fallback when the report is read; the emptied slots get new scenes and become READY again."""
     from environment import OcclusionEnv
     from SubProcVecEnv import SimpleVecEnv
@@ -168,31 +168,32 @@ def test_auto_reset_deferred_report_and_dry_reserve(ds):
     venv._reset_envs(list(range(N)), torch.zeros(N))
     venv._warm_reserve()
     eng = venv.engine
-    for i in (3, 7, 11):
+    fin = (3, 5, 7, 9, 11)
+    for i in fin:
         off = eng.scene_offset[i].clone()
         off[1, 0], off[2, 0] = 50.0, -50.0
         eng.scene_offset[i] = off
-    old_scenes = {i: venv.envs[i]._scene for i in (3, 7, 11)}
+    old_scenes = {i: venv.envs[i]._scene for i in fin}
     obs, rewards, dones, infos = venv.step(torch.zeros(N, 2, device="cuda"))
     assert venv._pending is not None, "report not read yet: the host ran ahead"
-    assert dones[[3, 7, 11]].all()
-    # device state already reset for the two lowest finished envs (pairing is in index order)
-    assert float(eng.camera_position[3].abs().sum()) == 0.0 and float(eng.camera_position[7].abs().sum()) == 0.0
-    assert sorted(eng.rs_state.tolist()) == [0, 0]
+    assert dones[list(fin)].all()
+    # device state already reset for the four lowest finished envs (pairing is in index order)
+    assert all(float(eng.camera_position[i].abs().sum()) == 0.0 for i in fin[:4])
+    assert sorted(eng.rs_state.tolist()) == [0, 0, 0, 0]
     # reading infos forces the bookkeeping, incl. the fallback reset of env 11
-    for i in (3, 7, 11):
+    for i in fin:
         assert infos[i]["terminal_observation"].shape == (1, 4, S, S)
         assert venv.envs[i]._scene is not old_scenes[i]
         assert float(eng.object_mass[i]) == pytest.approx(float(eng.full_reward[i]) + 1.0)
         ids, offs = venv.envs[i]._scene
         ref = eng.evaluate_scenes([ids], [offs], 4.0, 0.0, 0.0)
         assert torch.equal(ref["obs"][0], obs[i])
-    assert venv._pending is None and eng.rs_state.tolist() == [1, 1]  # refilled, under test
+    assert venv._pending is None and eng.rs_state.tolist() == [1, 1, 1, 1]  # refilled, under test
     # a few more steps: the rejection loop advances on the device until both slots are READY again
     for _ in range(12):
         venv.step(torch.zeros(N, 2, device="cuda"))
     venv._drain()
-    assert eng.rs_state.tolist() == [2, 2] and venv._rs_state.tolist() == [2, 2]
+    assert eng.rs_state.tolist() == [2, 2, 2, 2] and venv._rs_state.tolist() == [2, 2, 2, 2]
 
 
 def test_z_clipped_batch_properties():

@@ -70,9 +70,9 @@ def test_output_ring_never_changes_a_bit(ds):
     writes only the pixel blocks that meet this step's object rects or what the set held three steps ago): every
     observation, occlusion image, alpha plane, reward, done flag, gradient, terminal observation and reset image is
     bit-identical - through auto-resets from the reserve (full-frame commits into a set) and through the synchronous
-    fallback (12 envs finish at once against 8 reserve slots)."""
+    fallback (22 envs finish at once against 16 reserve slots)."""
     N, S, T = 64, 64, 30
-    push = {4: [3], 9: [10, 11], 15: list(range(20, 32)), 22: [5]}
+    push = {4: [3], 9: [10, 11], 15: list(range(20, 42)), 22: [5]}
     ref = _rollout(_make_venv(ds, N, S, ring=0), T, push)
     got = _rollout(_make_venv(ds, N, S, ring=3), T, push)
     n_done = 0
@@ -83,7 +83,7 @@ def test_output_ring_never_changes_a_bit(ds):
         for i in a["term"]:
             assert torch.equal(a["term"][i], b["term"][i]), (t, i)
         n_done += int(a["dones"].sum())
-    assert n_done >= 16
+    assert n_done >= 26
     # the ring really is a ring: the set of step t is the set of step t + 3
     venv = _make_venv(ds, 16, 64, ring=3)
     ptrs = [venv.step(torch.zeros(16, 2, device="cuda"))[0].data_ptr() for _ in range(6)]
@@ -168,8 +168,8 @@ def test_fused_step_equals_the_separate_calls(ds):
 
 def test_time_limit_resets_without_done(ds):
     """trainRL.py:22,191-229: an episode ends in env.reset() after max_ep_len steps, done or not, and is_terminal stays
-    False.  16 envs that cannot finish (zero actions) all reach max_ep_len = 4 together: two are reset from the reserve
-    on the device, fourteen by the synchronous fallback; every reset observation equals a reset render of the env's new
+    False.  16 envs that cannot finish (zero actions) all reach max_ep_len = 4 together: four are reset from the reserve
+    on the device, twelve by the synchronous fallback; every reset observation equals a reset render of the env's new
     scene, ``dones`` stays False, infos carry TimeLimit.truncated + terminal_observation, the counters restart."""
     N, S = 16, 64
     venv = _make_venv(ds, N, S)
@@ -229,3 +229,41 @@ def test_time_limit_on_the_host_driven_path(ds):
         assert infos[i]["TimeLimit.truncated"] is True and "terminal_observation" in infos[i]
         assert venv.envs[i]._scene is not scenes0[i]
     assert venv._age_host.tolist() == [0] * N
+
+
+def test_encoder_hook_on_the_gpu_rollout(ds):
+    """BatchedPPO(encoder=...) in the batched rollout (PPO.py:47,155-157: the buffer stores the frozen encoder's pooled
+    features): a small conv stub with the shape contract of the H1 fixture (obs (N,4,S,S) -> (N,256), captured from the
+    reference's FullNetwork in tests/golden/vecenv_golden.npz) feeds select_action, the records and the fused update."""
+    import os
+
+    from occlusionenv_amd import ppo, rollout
+
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vecenv_golden.npz"))
+    shapes = eval(str(gold["h1_shapes"]))  # noqa: S307 - [obs, pooled_features, ...] per case, from the reference
+    assert [s[0][1:] for s in shapes] == [[4, 64, 64], [4, 128, 128], [4, 128, 128]] and shapes[2][1] == [8, 256]
+    N, S, T = 16, 64, 6
+    venv = _make_venv(ds, N, S)
+    torch.manual_seed(0)
+    enc = torch.nn.Sequential(torch.nn.Conv2d(4, 16, 3, stride=2, padding=1), torch.nn.ReLU(), torch.nn.AdaptiveAvgPool2d(4),
+                              torch.nn.Flatten()).cuda()
+    seen = []
+
+    def encoder(obs):
+        seen.append((tuple(obs.shape), torch.is_grad_enabled()))
+        return enc(obs)
+
+    agent = ppo.BatchedPPO(device="cuda", seed=0, K_epochs=4, encoder=encoder)
+    recs = []
+    orig = agent.store
+    agent.store = lambda r: (recs.append(r.clone()), orig(r))[1]
+    stats = ppo.train_rollouts(venv, agent, n_updates=1, T=T, with_action_grad=True, max_ep_len=4)
+    assert len(seen) == T and all(s == ((N, 4, S, S), False) for s in seen)
+    assert len(recs) == T and recs[0].shape == (N, rollout.RECORD_FLOATS)
+    assert stats[0]["samples"] == T * N and np.isfinite(stats[0]["loss_last"])
+    # the stored features are the encoder's, not the 8x8 pooling stand-in's
+    obs0 = venv.reset()[:, 0]
+    f_enc = enc(obs0).detach()
+    feats, _, _ = agent.select_action(obs0)
+    assert torch.allclose(feats, f_enc, atol=1e-6) and not torch.allclose(feats, rollout.pooled_features(obs0), atol=1e-3)
+    assert venv.max_ep_len == 4  # the time limit train_rollouts switched on
