@@ -118,8 +118,8 @@ typedef struct OccScene {
 /* Caller-allocated scratch; sizes from occ_workspace_query(). */
 typedef struct OccWorkspace {
     float* rec;         /* (n_env,3,rec_cap,OCC_REC_STRIDE) projected face records */
-    uint32_t* rec_bbox; /* (n_env,3,rec_cap,4) per record: pixel bbox xl|yl<<16, xh|yh<<16|corner-cut bits<<28 (img <= 2048), key of its nearest vertex depth, flat-shading ambient+diffuse (f32 bits) */
-    uint32_t* scan;     /* (n_env,3,rec_cap,4) the same rows sorted front to back, .w = record index (the raster scan order) */
+    uint32_t* rec_bbox; /* (n_env,3,rec_cap,4) scan rows of the objects occ_sort_kernel re-sorted front to back (4 096..8 192 records); untouched otherwise (until ABI v7: a per-record bbox row, written for every record) */
+    uint32_t* scan;     /* (n_env,3,rec_cap,4) per record, in face order: pixel bbox xl|yl<<16, xh|yh<<16|corner-cut bits<<28 (img <= 2048), key of its nearest vertex depth, record index (the raster scan order unless re-sorted, see rec_bbox) */
     int32_t* nrec;      /* (n_env,3) */
     int32_t* objrect;   /* (n_env,3,4) block rect bx0,by0,bx1,by1 (inclusive, OCC_BLOCK-pixel units) */
     uint32_t* queue;    /* (8,16) one work-queue head per XCD group, a 64-B line each (zeroed by occ_render) */

@@ -183,10 +183,10 @@ __device__ __forceinline__ void combine_block(const RasterParams& P, int bpe, in
             ge = wpx * (2.0f * I * (g0 * dae[0] + g1 * dae[1] + g2 * dae[2]));
             ga = wpx * (2.0f * I * (g0 * daa[0] + g1 * daa[1] + g2 * daa[2]));
         }
-        lsum = wave_sum(lsum);
+        lsum = wave_sum_dpp(lsum);  // (DPP row operations: a fixed order, no LDS-crossbar round trips)
         if (GRAD) {
-            ge = wave_sum(ge);
-            ga = wave_sum(ga);
+            ge = wave_sum_dpp(ge);
+            ga = wave_sum_dpp(ga);
         }
         if (lane == 0) {
             s_red[wave][0] = lsum;
@@ -218,16 +218,21 @@ __device__ __forceinline__ void combine_block(const RasterParams& P, int bpe, in
     if (HARD && live && wr_o) {
         // [P3D] HardFlatShader + hard_rgb_blend; depth in channel 3 (environment.py:378)
         float cr = 1.f, cg = 1.f, cb = 1.f, depth = -1.f;
+        // where the three objects' records start: block-uniform (scalar loads), fetched before anything depends on the
+        // nearest object - as a per-pixel load it was one more dependent round trip between the depth and the record
+        size_t rb[3];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) rb[o] = rec_span(P.ws, cap, env * 3 + o).base;
         if (hrec >= 0) {
             const int eo = env * 3 + hobj;
-            const RecSpan span = rec_span(P.ws, cap, eo);
-            const float* __restrict__ r = P.ws.rec + (span.base + hrec) * OCC_REC_STRIDE;
+            const size_t rbase = hobj == 0 ? rb[0] : (hobj == 1 ? rb[1] : rb[2]);
+            const float* __restrict__ r = P.ws.rec + (rbase + hrec) * OCC_REC_STRIDE;
             const int fid = __float_as_int(r[R_ID]);
             const int mesh = P.sc.scene_mesh[eo];
             const int vo = P.sc.mesh_vert_off[mesh], fo = P.sc.mesh_face_off[mesh];
             const float ox = P.sc.scene_offset[eo * 3], oy = P.sc.scene_offset[eo * 3 + 1], oz = P.sc.scene_offset[eo * 3 + 2];
             // per-face shading terms from the setup kernel (flat_shade): one gather instead of face -> 3 vertices
-            const float amb_diff = __uint_as_float(reinterpret_cast<const uint4*>(P.ws.rec_bbox)[span.base + hrec].w);
+            const float amb_diff = r[R_AMB];
             const float spec = r[R_SPEC];
             const float* __restrict__ cm = P.cam + (size_t)env * OCC_CAM_STRIDE;
             // texel: white TexturesVertex interpolated with the (unclipped) barycentrics, or the face's atlas
@@ -394,9 +399,9 @@ __global__ __launch_bounds__(64) void occ_reduce_kernel(const float* __restrict_
         ge += v.y;
         ga += v.z;
     }
-    l = wave_sum(l);
-    ge = wave_sum(ge);
-    ga = wave_sum(ga);
+    l = wave_sum_dpp(l);
+    ge = wave_sum_dpp(ge);
+    ga = wave_sum_dpp(ga);
     if (lane == 0) {
         if (loss) loss[env] = l;
         if (grad_elaz) {

@@ -35,9 +35,9 @@ constexpr int R_X0 = 0, R_Y0 = 1, R_Z0 = 2, R_X1 = 3, R_Y1 = 4, R_Z1 = 5, R_X2 =
 constexpr int R_ID = 9;        // original face id in its pool mesh (int bits)
 constexpr int R_FLAGS = 10;    // int bits: 1 = first of a clipped pair, 2 = second, 4 = z-clipped piece
 constexpr int R_INV_AREA = 11; // 1 / (E(v2; v0, v1) + kEpsilon)
-constexpr int R_BX0 = 12, R_BX1 = 13, R_BY0 = 14, R_BY1 = 15;  // bbox +- sqrt(blur)
+constexpr int R_AMB = 12;      // ambient + diffuse term of the flat-shaded face (13..15 unused; until round 4: the float bbox +- sqrt(blur))
 constexpr int R_IL01 = 16, R_IL02 = 17, R_IL12 = 18;           // 1/|b-a|^2, or -1 when |b-a|^2 <= kEpsilon
-constexpr int R_SPEC = 19;     // specular term of the flat-shaded face (ambient + diffuse sits in rec_bbox[].w)
+constexpr int R_SPEC = 19;     // specular term of the flat-shaded face
 constexpr int R_TAN = 20;      // 12 floats: per vertex (dx/del, dy/del, dx/daz, dy/daz)
 constexpr int kRecParts = 8;   // 16-byte parts per record: 128 B = one cache line
 constexpr int kRecPad = 9;     // LDS stride (parts) of a record staged by the setup kernel: bank-conflict-free

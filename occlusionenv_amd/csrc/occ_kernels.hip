@@ -275,7 +275,7 @@ extern "C" int occ_step(const OccScene* scene, const OccCameraArgs* camera, floa
     OCC_DBG_SYNC("setup");
     if (scene->rec_cap >= kSortMin) {
         // dense objects only: front-to-back scan order (LDS sort buffer: 8192 keys = 64 KiB)
-        const int sort_cap = 8192;
+        const int sort_cap = kSortCap;
         hipLaunchKernelGGL(occ_sort_kernel, dim3(N * 3), dim3(256), (size_t)sort_cap * sizeof(unsigned long long), st,
                            *scene, *ws, sort_cap);
         OCC_DBG_SYNC("sort");

@@ -247,7 +247,9 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
         if (!OCC_BOUND(!(n < 0 || n > span.cap), 47, n, eo)) continue;
         OCC_STAT(0, 1);  // work items
         const float4* __restrict__ recs4 = reinterpret_cast<const float4*>(P.ws.rec + span.base * OCC_REC_STRIDE);
-        const uint4* __restrict__ scan = reinterpret_cast<const uint4*>(P.ws.scan) + span.base;
+        // scan order: face order, or front to back for an object that occ_sort_kernel re-sorted (rows in rec_bbox)
+        const uint4* __restrict__ scan =
+            reinterpret_cast<const uint4*>(scan_is_sorted(n) ? (const uint32_t*)P.ws.rec_bbox : (const uint32_t*)P.ws.scan) + span.base;
 
         wave_lds_sync();  // the previous item's readers of the LDS state are done
         // [P3D] pixel centre of the pixel this lane owns, in NDC, +X left, +Y up: same expression as the

@@ -164,7 +164,7 @@ __device__ __forceinline__ Shade flat_shade(const float* w0, const float* w1, co
 }
 
 template <bool GRAD>
-__device__ __forceinline__ void write_record(float* __restrict__ r, uint4* __restrict__ bb, uint4* __restrict__ scan_row,
+__device__ __forceinline__ void write_record(float* __restrict__ r, uint4* __restrict__ scan_row,
                                              int pos, const Tri& t, int face_id, int flags, Shade sh) {
     const float x0 = t.v[0].x, y0 = t.v[0].y, x1 = t.v[1].x, y1 = t.v[1].y, x2 = t.v[2].x, y2 = t.v[2].y;
     // [P3D] BarycentricCoordsForward: area = EdgeFunction(v2; v0, v1) + kEpsilon
@@ -177,8 +177,10 @@ __device__ __forceinline__ void write_record(float* __restrict__ r, uint4* __res
     r4[0] = make_float4(x0, y0, t.v[0].z, x1);
     r4[1] = make_float4(y1, t.v[1].z, x2, y2);
     r4[2] = make_float4(t.v[2].z, __int_as_float(face_id), __int_as_float(flags), 1.0f / area);
-    r4[3] = make_float4(fmin3(x0, x1, x2) - kSqrtBlur, fmax3(x0, x1, x2) + kSqrtBlur, fmin3(y0, y1, y2) - kSqrtBlur,
-                        fmax3(y0, y1, y2) + kSqrtBlur);
+    // part 3: the face's ambient + diffuse shading term.  (Until round 4 this part held [P3D]'s float bbox +- sqrt(blur),
+    // which no kernel read any more, and the term travelled in a 16-byte row of its own per record - rec_bbox, a tenth of
+    // the bytes the kernel writes.)
+    r4[3] = make_float4(sh.amb_diff, 0.f, 0.f, 0.f);
     r4[4] = make_float4(l01 <= kEpsilon ? -1.0f : 1.0f / l01, l02 <= kEpsilon ? -1.0f : 1.0f / l02,
                         l12 <= kEpsilon ? -1.0f : 1.0f / l12, sh.spec);
     if (GRAD) {
@@ -186,7 +188,6 @@ __device__ __forceinline__ void write_record(float* __restrict__ r, uint4* __res
         r4[6] = make_float4(t.v[1].t[0], t.v[1].t[1], t.v[1].t[2], t.v[1].t[3]);
         r4[7] = make_float4(t.v[2].t[0], t.v[2].t[1], t.v[2].t[2], t.v[2].t[3]);
     }
-    *bb = make_uint4(t.bbox.x, t.bbox.y, t.bbox.z, __float_as_uint(sh.amb_diff));  // .w: ambient + diffuse of the face
     // scan row in face order (occ_sort_kernel re-orders dense objects): (pixel bbox, nearest depth key, record index)
     *scan_row = make_uint4(t.bbox.x, t.bbox.y, t.bbox.z, (uint32_t)pos);
 }
@@ -194,9 +195,9 @@ __device__ __forceinline__ void write_record(float* __restrict__ r, uint4* __res
 // Parts 0..4 of a record (positions, id, flags, 1 / area, float bbox, 1 / |edge|^2 x 3, specular term) and its bbox and
 // scan rows: write_record without the tangents.  The setup kernel stages a record in two pieces - these five parts,
 // then the three tangent parts - through a five-part LDS slot (see there).
-__device__ __forceinline__ void write_record_lo(float4* __restrict__ r4, uint4* __restrict__ bb, uint4* __restrict__ scan_row,
+__device__ __forceinline__ void write_record_lo(float4* __restrict__ r4, uint4* __restrict__ scan_row,
                                                 int pos, const Tri& t, int face_id, int flags, Shade sh) {
-    write_record<false>(reinterpret_cast<float*>(r4), bb, scan_row, pos, t, face_id, flags, sh);
+    write_record<false>(reinterpret_cast<float*>(r4), scan_row, pos, t, face_id, flags, sh);
 }
 
 // union pixel bbox and smallest depth key of every 64-entry chunk of the scan order (two-level scan)
@@ -317,19 +318,22 @@ __global__ __launch_bounds__(1024) void occ_recoff_kernel(OccScene sc, long long
 #define OCC_SORT_MIN 4096
 #endif
 constexpr int kSortMin = OCC_SORT_MIN;
+constexpr int kSortCap = 8192;  // records of one object that the sort kernel's LDS holds (64 KiB of keys)
+// an object whose scan order occ_sort_kernel has re-sorted: its sorted rows are in OccWorkspace.rec_bbox
+__host__ __device__ __forceinline__ bool scan_is_sorted(int nrec) { return nrec >= kSortMin && nrec <= kSortCap; }
 __global__ __launch_bounds__(256) void occ_sort_kernel(OccScene sc, OccWorkspace ws, int sort_cap) {
     extern __shared__ unsigned long long s_keys[];  // sort_cap keys: depth key << 32 | record index
     const int eo = blockIdx.x;
     const int nr = ws.nrec[eo];
-    if (nr < kSortMin) return;
+    if (!scan_is_sorted(nr) || sort_cap < kSortCap) return;
     int p2 = 1;
     while (p2 < nr) p2 <<= 1;
-    if (p2 > sort_cap) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const RecSpan span = rec_span(ws, sc.rec_cap, eo);
-    const uint4* __restrict__ bbs = reinterpret_cast<const uint4*>(ws.rec_bbox) + span.base;
-    uint4* __restrict__ scan = reinterpret_cast<uint4*>(ws.scan) + span.base;
-    for (int i = tid; i < p2; i += 256) s_keys[i] = i < nr ? (((unsigned long long)bbs[i].z << 32) | (unsigned)i) : ~0ull;
+    // the rows in face order (written by the setup kernel) -> the same rows front to back, in the object's span of rec_bbox
+    const uint4* __restrict__ rows = reinterpret_cast<const uint4*>(ws.scan) + span.base;
+    uint4* __restrict__ sorted = reinterpret_cast<uint4*>(ws.rec_bbox) + span.base;
+    for (int i = tid; i < p2; i += 256) s_keys[i] = i < nr ? (((unsigned long long)rows[i].z << 32) | (unsigned)i) : ~0ull;
     __syncthreads();
     for (int k = 2; k <= p2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -349,11 +353,11 @@ __global__ __launch_bounds__(256) void occ_sort_kernel(OccScene sc, OccWorkspace
     }
     for (int i = tid; i < nr; i += 256) {
         const int j = (int)(s_keys[i] & 0xFFFFFFFFu);
-        const uint4 bb = bbs[j];
-        scan[i] = make_uint4(bb.x, bb.y, bb.z, (uint32_t)j);
+        const uint4 bb = rows[j];
+        sorted[i] = make_uint4(bb.x, bb.y, bb.z, (uint32_t)j);
     }
     __syncthreads();
-    chunk_boxes(scan, reinterpret_cast<uint4*>(ws.rec_cbox) + span.cbox, nr, wave, lane);
+    chunk_boxes(sorted, reinterpret_cast<uint4*>(ws.rec_cbox) + span.cbox, nr, wave, lane);
 }
 
 constexpr int kSetupVcapMax = 4096;  // vertices of one object that the setup kernel stages in LDS (48 KB) at most
@@ -557,7 +561,6 @@ __global__ __launch_bounds__(TB, 4) void occ_setup_kernel(OccScene sc, const flo
     }
     __syncthreads();
     float* __restrict__ rec = ws.rec + span.base * OCC_REC_STRIDE;
-    uint4* __restrict__ bbs = reinterpret_cast<uint4*>(ws.rec_bbox) + span.base;
     uint4* __restrict__ scan = reinterpret_cast<uint4*>(ws.scan) + span.base;
     int total = 0;
     bool overflow = false;
@@ -681,10 +684,10 @@ __global__ __launch_bounds__(TB, 4) void occ_setup_kernel(OccScene sc, const flo
                     }
                     if (staged) {  // parts 0..4 now; the tangents follow once the wave has copied these out
                         rec_fast = true;
-                        write_record_lo(&s_rec[(wave * 64 + pre) * kHalfPad], bbs + pos, scan + pos, pos, tri, f, 0, sh);
+                        write_record_lo(&s_rec[(wave * 64 + pre) * kHalfPad], scan + pos, pos, tri, f, 0, sh);
                     } else {
                         float4* __restrict__ r4 = reinterpret_cast<float4*>(rec + (size_t)pos * OCC_REC_STRIDE);
-                        write_record_lo(r4, bbs + pos, scan + pos, pos, tri, f, 0, sh);
+                        write_record_lo(r4, scan + pos, pos, tri, f, 0, sh);
                         if (GRAD) tangents(r4 + 5);
                     }
                     x0 = tri.tx0; y0 = tri.ty0; x1 = tri.tx1; y1 = tri.ty1;
@@ -692,10 +695,10 @@ __global__ __launch_bounds__(TB, 4) void occ_setup_kernel(OccScene sc, const flo
                     Tri tmp[2];
                     int fl[2];
                     clip_face_slow<GRAD>(pool_faces, pool_verts, c, S, vo, fo, f, ox, oy, oz, tmp, fl);
-                    write_record<GRAD>(rec + (size_t)pos * OCC_REC_STRIDE, bbs + pos, scan + pos, pos, tmp[0], f, fl[0], sh);
+                    write_record<GRAD>(rec + (size_t)pos * OCC_REC_STRIDE, scan + pos, pos, tmp[0], f, fl[0], sh);
                     x0 = tmp[0].tx0; y0 = tmp[0].ty0; x1 = tmp[0].tx1; y1 = tmp[0].ty1;
                     if (cnt == 2) {
-                        write_record<GRAD>(rec + (size_t)(pos + 1) * OCC_REC_STRIDE, bbs + pos + 1, scan + pos + 1, pos + 1,
+                        write_record<GRAD>(rec + (size_t)(pos + 1) * OCC_REC_STRIDE, scan + pos + 1, pos + 1,
                                            tmp[1], f, fl[1], sh);
                         x0 = min(x0, tmp[1].tx0); y0 = min(y0, tmp[1].ty0);
                         x1 = max(x1, tmp[1].tx1); y1 = max(y1, tmp[1].ty1);

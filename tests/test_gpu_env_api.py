@@ -592,7 +592,7 @@ def test_work_item_order_is_a_cost_sorted_permutation_of_all_tiles(mesh, S):
     assert cls.max() > cls.min()
     # the class bounds the faces from above: count, per tile, the records whose pixel bbox touches it
     rec_off = eng._rec_tensors["rec_off"].cpu().numpy().view(np.int64)
-    bbox = eng._rec_tensors["rec_bbox"].cpu().numpy().view(np.uint32).reshape(-1, 4)
+    bbox = eng._rec_tensors["scan"].cpu().numpy().view(np.uint32).reshape(-1, 4)  # rows in face order: (pixel bbox, depth key, index)
 
     def bound(c):  # occ_common.hpp: ord_class_bound
         if c <= 0:

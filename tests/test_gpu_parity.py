@@ -184,6 +184,40 @@ def test_small_log_build_forces_inloop_compaction():
     _check(json.loads(line[3:]))
 
 
+@pytest.mark.xfail(strict=True, reason="known limitation, not a tie: with the camera INSIDE the scene (radius 2.5, objects out to z = 2) "
+                   "the forward-mode action gradient is off by 4.6e-4 of its norm - 456 eps x M against the arbiter's 256 "
+                   "(the f32 oracle: 16).  Near vertices have large NDC tangents that are nearly equal across the candidates "
+                   "of a pixel; the forward sweep multiplies every candidate's small distance gradient by them BEFORE the sum "
+                   "in which they cancel, autograd's reverse sweep sums per vertex first.  Same numbers with round 3's kernels. "
+                   "The noise band stays frozen (tests/test_host_logic.py); DESIGN.md section 2.")
+def test_known_gradient_noise_excess_with_the_camera_inside_the_scene():
+    """Found by round 4's wide sweep (profiles/r04_parity_sweep.txt: 1 violation in 320 cases, seed 6011).  Every image,
+    the loss and the reward of the case are within tolerance; only d reward / d action of env 0 exceeds the arbiter's
+    bound (1.42e-4 against 1.11e-4).  strict: the day the gradient gets better this test must be turned into a plain one."""
+    res = run_parity_case(n_env=2, img=128, seed=6011, mesh="textured", az_range=3.0, radius=2.5, faces_per_pixel=100)
+    bad = [v for v in __import__("tests.parity_utils", fromlist=["violations"]).violations(res)]
+    assert all(v.startswith("grad:") for v in bad), bad  # nothing but the gradient
+    _check(res)
+
+
+def test_sorted_scan_order_build_matches_the_oracle():
+    """Same sources built with OCC_SORT_MIN = 1 024 (production: 4 096 records): the 5 120-face meshes of the case are
+    "dense" - occ_sort_kernel re-sorts their scan rows front to back into rec_bbox, the raster kernel walks those rows,
+    keeps per-pixel bounds and prunes.  Results must pass the same parity check (the order of candidates changes the
+    rounding, not the set of the K nearest)."""
+    lib = os.path.join(ROOT, "occlusionenv_amd", "libocc_hip_sortmin.so")
+    assert os.path.exists(lib), "run __graft_entry__.build() first"
+    code = ("import json,sys; sys.path.insert(0, %r); from tests.parity_utils import run_parity_case; "
+            "print('RES'+json.dumps(run_parity_case(n_env=2, img=64, seed=2, mesh='synthetic')));"
+            "print('RES'+json.dumps(run_parity_case(n_env=2, img=96, seed=12, mesh='mixed', faces_per_pixel=50)))" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OCC_HIP_LIB=lib), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("RES")]
+    assert len(lines) == 2
+    for line in lines:
+        _check(json.loads(line[3:]))
+
+
 def test_corner_cut_never_changes_a_bit():
     """The setup kernel marks corner pixels of a face's pixel box that lie beyond the blur disc of the face's own box
     (occ_setup.hpp: finish_tri) and the raster kernel leaves those (face, pixel) pairs out of its rounds.  They were
