@@ -152,6 +152,9 @@ class SimpleVecEnv(VecEnv):
         # optional torch.cuda.Event: recorded by an asynchronous consumer of the last step's ``obs`` (another stream)
         # once it has read it; the in-place reset fallback below waits on it before overwriting rows of ``obs``
         self.obs_consumer_event = None
+        # output ring: the consumer event of the step that last used each output set (a set is not overwritten before
+        # the side stream that still reads it - RecordExchange packs step k's records while step k + 1 renders - is done)
+        self._ring_events, self._ring_last = None, None
 
     def step_async(self, actions):
         self.actions = actions
@@ -166,6 +169,7 @@ class SimpleVecEnv(VecEnv):
         if k == 1 or k < 0:
             raise ValueError("output ring: 0 (fresh outputs) or k >= 2 sets")
         eng.output_ring, eng._ring, eng._ring_pos = int(k), None, 0
+        self._ring_events, self._ring_last = None, None
 
     def stagger_ages(self, seed=None) -> None:
         """Spread the envs' episode ages uniformly over [0, max_ep_len): envs that were reset together would otherwise
@@ -327,6 +331,16 @@ class SimpleVecEnv(VecEnv):
                 self._warm_reserve()
             # the report of the previous step is read as late as possible: after this step's outputs are allocated
             # and its launch arguments are built, right before its first kernel launch
+            if eng.output_ring:
+                if self._ring_events is None or len(self._ring_events) != eng.output_ring:
+                    self._ring_events, self._ring_last = [None] * eng.output_ring, None
+                if self._ring_last is not None:  # what the caller attached after the previous step belongs to ITS set
+                    self._ring_events[self._ring_last] = self.obs_consumer_event
+                slot = eng._ring_pos  # the set this step writes
+                if self._ring_events[slot] is not None:
+                    torch.cuda.current_stream(eng.device).wait_event(self._ring_events[slot])
+                    self._ring_events[slot] = None
+                self._ring_last = slot
             empty = []
 
             def pre_launch():  # the GPU idles from the report's arrival to this step's first launch: only what must precede it

@@ -36,8 +36,11 @@ __device__ __forceinline__ void combine_block(const RasterParams& P, int bpe, in
 // hold their background values) only the pixel blocks between the first and the last row that this step's footprint or
 // one of those rects touches are visited at all: a launch of one thread block per 256 pixels spent most of its time
 // starting 57 000 blocks that read six rects and exit (three quarters of a 128 x 128 frame are background).
+// (__launch_bounds__(256, 6): 74 registers instead of 83, six waves per SIMD instead of five - the kernel lives on memory
+// latency: -15 us.  Eight waves (64 registers, 48 B of scratch): the same.  Issuing the next pixel block's plane loads
+// before working on the current one - software pipelining at 94 - 102 registers - gained nothing over that.)
 template <bool SOFT, bool HARD, bool GRAD>
-__global__ __launch_bounds__(256) void occ_combine_kernel(RasterParams P, int bpe, int G) {
+__global__ __launch_bounds__(256, 6) void occ_combine_kernel(RasterParams P, int bpe, int G) {
     __shared__ float s_red[4][3];
     const int tid = threadIdx.x;
     const int env = blockIdx.x / G, g = blockIdx.x - env * G;

@@ -267,3 +267,38 @@ def test_encoder_hook_on_the_gpu_rollout(ds):
     feats, _, _ = agent.select_action(obs0)
     assert torch.allclose(feats, f_enc, atol=1e-6) and not torch.allclose(feats, rollout.pooled_features(obs0), atol=1e-3)
     assert venv.max_ep_len == 4  # the time limit train_rollouts switched on
+
+
+def test_ring_set_waits_for_its_side_stream_consumer(ds):
+    """With the output ring a step's ``obs`` is overwritten k steps later.  A consumer on another stream (bench.py's
+    RecordExchange packs step t's records while step t + 1 renders) announces itself through ``obs_consumer_event``;
+    the env keeps that event with the output set and makes the step that reuses the set wait for it.  Here the consumer
+    is artificially slow (it sleeps on the device before it reads): what it reads must still be step t's observation."""
+    N, S, k = 16, 64, 2
+    venv = _make_venv(ds, N, S, ring=k)
+    ref = _make_venv(ds, N, S, ring=0)
+    side = torch.cuda.Stream()
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    copies, expect = [], []
+    alive = torch.ones(N, dtype=torch.bool, device="cuda")  # (an env that finishes draws its next scene from the RNG the two
+    for t in range(6):                                       #  envs share: only envs that never finished are compared)
+        a = torch.randn(N, 2, device="cuda", generator=gen)
+        obs, _, d1, _ = venv.step(a)
+        o2, _, d2, _ = ref.step(a)
+        alive &= ~(d1 | d2)
+        expect.append((o2.clone(), alive.clone()))
+        produced = torch.cuda.Event()
+        produced.record()
+        with torch.cuda.stream(side):
+            side.wait_event(produced)
+            torch.cuda._sleep(20_000_000)  # ~10 ms: far longer than a step - the ring set comes round again before this ends
+            copies.append(obs.clone())
+            ev = torch.cuda.Event()
+            ev.record(side)
+        obs.record_stream(side)
+        venv.obs_consumer_event = ev
+    torch.cuda.synchronize()
+    assert int(alive.sum()) >= N // 2
+    for t, (c, (e, ok)) in enumerate(zip(copies, expect)):
+        assert torch.equal(c[ok], e[ok]), t
+        assert t == 0 or not torch.equal(c[ok], expect[t - 1][0][ok])  # (the observation does change from step to step)
