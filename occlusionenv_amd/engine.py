@@ -109,6 +109,7 @@ class OcclusionEngine:
         self._arect = [torch.tensor([self.S, self.S, -1, -1], dtype=torch.int32, device=d).repeat(NT, 1).contiguous()
                        for _ in range(2)]
         self._arect_cur = 0
+        self._full_rect = None
         # scene description
         self.scene_mesh, self.scene_offset = self._mesh_all[:N], self._off_all[:N]
         # internal buffers
@@ -162,7 +163,11 @@ class OcclusionEngine:
 
     def _alpha_touch(self, rows) -> None:
         """Rows of the alphas state were written as whole frames by something other than a tracked launch."""
-        self._arect[self._arect_cur][rows] = torch.tensor([0, 0, self.S - 1, self.S - 1], dtype=torch.int32, device=self.device)
+        if not self.R:  # no reserve = no tracked launch ever reads the rects (a single env: nothing extra on its step)
+            return
+        if self._full_rect is None:
+            self._full_rect = torch.tensor([0, 0, self.S - 1, self.S - 1], dtype=torch.int32, device=self.device)
+        self._arect[self._arect_cur][rows] = self._full_rect
 
     def _ring_slot(self) -> dict:
         """The output set of this step (output_ring >= 2): persistent obs / full_state holding background outside their rects."""
