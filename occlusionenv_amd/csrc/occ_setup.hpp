@@ -16,9 +16,13 @@ struct VVert {  // view-space vertex with tangents
 
 // NB a surviving unclipped face is projected twice: before the block-wide compaction barrier, where finish_tri()
 // takes the ONE visibility decision and derives the conservative pixel bbox (both cross the barrier: the count in a
-// register, the bbox through LDS), and after it, for the record's DATA only (the world corners, not the projections,
-// are what a face keeps in registers).  The two inlined copies may round differently in the last bit (FMA
-// contraction); nothing is decided from the second one, and the bbox carries 1e-3 px of slack.
+// register, the bbox through LDS), and after it, for the record's DATA only (the world corners and the three 1 / z_view,
+// not the projections, are what a face keeps in registers).  The two inlined copies may round differently in the last
+// bit (FMA contraction); nothing is decided from the second one, and the bbox carries 1e-3 px of slack.
+// DIVISIONS (round 4): an IEEE f32 division is ten instructions, one of them quarter-rate, and a 512-face round used to
+// hold seventeen: 1 / z per corner three times over (culling, record, tangents), four pixel centres / S in finish_tri,
+// 1 / area and 3 x 1 / |edge|^2 of the record.  Now seven (1 / z once per corner, carried along; the centres multiply
+// by 1 / S, computed once per block): step -24 us on the bench, records bit-identical (scripts/dbg/ab_outputs.py).
 __device__ __forceinline__ void project_pos(const VVert& q, PVert& p, float& iz) {
     // [P3D] x_ndc = x_view * s / z_view  
     iz = 1.0f / q.v[2];
@@ -26,11 +30,21 @@ __device__ __forceinline__ void project_pos(const VVert& q, PVert& p, float& iz)
     p.y = q.v[1] * kProjScale * iz;
     p.z = q.v[2];
 }
+// (iz_in: 1 / z_view of this vertex if the caller has it already - an IEEE division costs ten instructions, one of them
+// quarter-rate, and the setup kernel used to evaluate it three times per corner; nullptr = divide here)
 template <bool GRAD>
-__device__ __forceinline__ PVert project(const VVert& q) {
+__device__ __forceinline__ PVert project(const VVert& q, const float* iz_in = nullptr, float* iz_out = nullptr) {
     PVert p;
     float iz;
-    project_pos(q, p, iz);
+    if (iz_in) {
+        iz = *iz_in;
+        p.x = q.v[0] * kProjScale * iz;
+        p.y = q.v[1] * kProjScale * iz;
+        p.z = q.v[2];
+    } else {
+        project_pos(q, p, iz);
+    }
+    if (iz_out) *iz_out = iz;
     if (GRAD) {
         p.t[0] = (kProjScale * q.de[0] - p.x * q.de[2]) * iz;
         p.t[1] = (kProjScale * q.de[1] - p.y * q.de[2]) * iz;
@@ -70,11 +84,13 @@ struct Tri {
     int tx0, ty0, tx1, ty1;
 };
 
+__device__ __forceinline__ float tri_lim(int S) { return 1.0f - 1.0f / (float)S; }  // outermost pixel centre
+
 // Returns false if the triangle can never be matched to a pixel (culled / degenerate / off screen).  EVERY field
 // is filled with in-range values either way (clamped pixel bbox), whatever the verdict.  occ_setup_kernel calls this
 // ONCE per unclipped face, before the compaction barrier; the verdict and the pixel bbox cross the barrier (count
 // in a register, bbox through LDS) and are not derived again.
-__device__ __forceinline__ bool finish_tri(Tri& t, int S) {
+__device__ __forceinline__ bool finish_tri(Tri& t, int S, float lim, float ifS) {  // lim = tri_lim(S), ifS = 1 / S
     const float x0 = t.v[0].x, y0 = t.v[0].y, x1 = t.v[1].x, y1 = t.v[1].y, x2 = t.v[2].x, y2 = t.v[2].y;
     // [P3D] face_area = EdgeFunction(v0; v1, v2); back faces are culled (environment.py:253,271)
     const float area = (x0 - x1) * (y2 - y1) - (y0 - y1) * (x2 - x1);
@@ -82,7 +98,6 @@ __device__ __forceinline__ bool finish_tri(Tri& t, int S) {
     vis = vis && !(fmax3(t.v[0].z, t.v[1].z, t.v[2].z) < 0.0f);
     const float bx0 = fmin3(x0, x1, x2) - kSqrtBlur, bx1 = fmax3(x0, x1, x2) + kSqrtBlur;
     const float by0 = fmin3(y0, y1, y2) - kSqrtBlur, by1 = fmax3(y0, y1, y2) + kSqrtBlur;
-    const float lim = 1.0f - 1.0f / (float)S;  // outermost pixel centre
     vis = vis && !(bx1 < -lim || bx0 > lim || by1 < -lim || by0 > lim);
     // pixel index of an NDC coordinate: u(f) = (S-1) - ((f+1)*S - 1)/2   (decreasing)
     const float fS = (float)S;
@@ -110,7 +125,8 @@ __device__ __forceinline__ bool finish_tri(Tri& t, int S) {
     uint32_t corner = 0u;
 #ifndef OCC_NO_CORNER_CUT  // (the A/B build of tests/test_gpu_parity.py: results must not change by a bit)
     {
-        auto ctr = [&](int i) { return -1.0f + (2.0f * (float)(S - 1 - i) + 1.0f) / fS; };  // pixel centre, as the raster kernel
+        // pixel centre (the raster kernel divides by S; 1 / S is exact for a power of two, and the 1e-3 margin below covers an ulp)
+        auto ctr = [&](int i) { return -1.0f + (2.0f * (float)(S - 1 - i) + 1.0f) * ifS; };
         auto gap = [](float lo, float hi, float c) { return fmaxf(fmaxf(lo - c, c - hi), 0.0f); };
         const float fx0 = fmin3(x0, x1, x2), fx1 = fmax3(x0, x1, x2), fy0 = fmin3(y0, y1, y2), fy1 = fmax3(y0, y1, y2);
         const float gxl = gap(fx0, fx1, ctr(xl)), gxh = gap(fx0, fx1, ctr(xh));
@@ -444,7 +460,7 @@ __device__ __attribute__((noinline)) int clip_face_slow(const int* __restrict__ 
         out[0].v[0] = cut_edge<GRAD>(q[i1], q[i2]);
         out[0].v[1] = cut_edge<GRAD>(q[i1], q[i3]);
         out[0].v[2] = project<GRAD>(q[i1]);
-        return finish_tri(out[0], S) ? 1 : 0;
+        return finish_tri(out[0], S, tri_lim(S), 1.0f / (float)S) ? 1 : 0;
     }
     if (nb == 1) {
         // case 4: p1 = the vertex behind; quad -> (p4, p2, p5), (p5, p2, p3)
@@ -457,7 +473,7 @@ __device__ __attribute__((noinline)) int clip_face_slow(const int* __restrict__ 
         Tri ta, tb;
         ta.v[0] = p4; ta.v[1] = p2; ta.v[2] = p5;
         tb.v[0] = p5; tb.v[1] = p2; tb.v[2] = p3;
-        const bool oka = finish_tri(ta, S), okb = finish_tri(tb, S);
+        const bool oka = finish_tri(ta, S, tri_lim(S), 1.0f / (float)S), okb = finish_tri(tb, S, tri_lim(S), 1.0f / (float)S);
         if (oka && okb) {
             out[0] = ta; out[1] = tb;
             flags[0] = FLAG_PAIR_FIRST | FLAG_CLIPPED; flags[1] = FLAG_PAIR_SECOND | FLAG_CLIPPED;
@@ -544,6 +560,7 @@ __global__ __launch_bounds__(TB, 4) void occ_setup_kernel(OccScene sc, const flo
     };
     const RecSpan span = rec_span(ws, sc.rec_cap, eo);
     const int S = sc.img, rec_cap = span.cap;
+    const float lim = tri_lim(S), ifS = 1.0f / (float)S;  // (once per block, not once per round)
     const bool ordered = ws.order != nullptr;
     const int tiles_side = S / 8;
     int cs = 0;  // tiles per cell side = 1 << cs
@@ -577,7 +594,8 @@ __global__ __launch_bounds__(TB, 4) void occ_setup_kernel(OccScene sc, const flo
         const int f = base + tid;
         int cnt = 0;
         bool slow = false;
-        float w0[3], w1[3], w2[3];  // world-space corners: all that a surviving face carries across the barrier
+        float w0[3], w1[3], w2[3];  // world-space corners and 1 / z_view: all that a surviving face carries across the barrier
+        float iz0 = 0.f, iz1 = 0.f, iz2 = 0.f;
         const int c0 = vi0, c1 = vi1, c2 = vi2;
         if (f + TB < nF) {
             const int* pf = pool_faces + (size_t)(fo + f + TB) * 3;
@@ -594,10 +612,10 @@ __global__ __launch_bounds__(TB, 4) void occ_setup_kernel(OccScene sc, const flo
             view_from_world<false>(C, w2, q2);
             slow = (q0.v[2] < kZClip) || (q1.v[2] < kZClip) || (q2.v[2] < kZClip);
             if (!slow) {
-                tri.v[0] = project<false>(q0);
-                tri.v[1] = project<false>(q1);
-                tri.v[2] = project<false>(q2);
-                cnt = finish_tri(tri, S) ? 1 : 0;
+                tri.v[0] = project<false>(q0, nullptr, &iz0);
+                tri.v[1] = project<false>(q1, nullptr, &iz1);
+                tri.v[2] = project<false>(q2, nullptr, &iz2);
+                cnt = finish_tri(tri, S, lim, ifS) ? 1 : 0;
                 s_box[tid] = make_uint2(tri.bbox.x, tri.bbox.y);  // read back by this thread only, after the barrier
             }
         }
@@ -650,13 +668,13 @@ __global__ __launch_bounds__(TB, 4) void occ_setup_kernel(OccScene sc, const flo
             VVert q;
             PVert pk;
             view_from_world<true>(C, w0, q);
-            pk = project<true>(q);
+            pk = project<true>(q, &iz0);
             r5[0] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
             view_from_world<true>(C, w1, q);
-            pk = project<true>(q);
+            pk = project<true>(q, &iz1);
             r5[1] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
             view_from_world<true>(C, w2, q);
-            pk = project<true>(q);
+            pk = project<true>(q, &iz2);
             r5[2] = make_float4(pk.t[0], pk.t[1], pk.t[2], pk.t[3]);
         };
         if (cnt >= 1) {
@@ -669,11 +687,11 @@ __global__ __launch_bounds__(TB, 4) void occ_setup_kernel(OccScene sc, const flo
                     {
                         VVert q;
                         view_from_world<false>(C, w0, q);
-                        tri.v[0] = project<false>(q);
+                        tri.v[0] = project<false>(q, &iz0);
                         view_from_world<false>(C, w1, q);
-                        tri.v[1] = project<false>(q);
+                        tri.v[1] = project<false>(q, &iz1);
                         view_from_world<false>(C, w2, q);
-                        tri.v[2] = project<false>(q);
+                        tri.v[2] = project<false>(q, &iz2);
                         const uint2 bx = s_box[tid];
                         const uint32_t zb = __float_as_uint(fmin3(tri.v[0].z, tri.v[1].z, tri.v[2].z));
                         tri.bbox = make_uint4(bx.x, bx.y, (zb & 0x80000000u) ? ~zb : (zb | 0x80000000u), 0u);

@@ -9,13 +9,16 @@ ROOTD=$PWD
 OUT=$ROOTD/gpurun_out/$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 2 --no-cpu-baseline"
+ARGS="--steps 10 --warmup 2 --no-cpu-baseline"          # PMC passes: counters are per launch, every kernel is replayed
+TRACE_ARGS="--steps 40 --warmup 4 --no-cpu-baseline"    # --stats averages over the warm-up launches too: dilute them
 timeout -k 10 500 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 prof() {  # subdir, rocprofv3 options..., then bench args after --
   d=$1; shift
   (cd /tmp && timeout -k 10 300 rocprofv3 "$@" --output-format csv -d "$OUT/$d" -- python "$ROOTD/bench.py" $ARGS > "$OUT/$d.log" 2>&1)
 }
+SAVED=$ARGS; ARGS=$TRACE_ARGS
 prof trace --kernel-trace --stats
+ARGS=$SAVED
 prof pmc_fetch --kernel-trace --pmc FETCH_SIZE
 prof pmc_write --kernel-trace --pmc WRITE_SIZE
 prof pmc_sq --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS
