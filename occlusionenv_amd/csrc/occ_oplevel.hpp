@@ -317,6 +317,164 @@ __global__ __launch_bounds__(64) void occ_rast_tiled_fwd_kernel(KbufArgs a, int 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Sub-pixel meshes (round 4): occ_rast_quad_fwd_kernel - one wave per (mesh, 4x4-pixel tile), FOUR faces in flight.
+// Without clipped-face pairs (clipped_faces_neighbor_idx == NULL: the case of every scene the camera is not inside) the
+// K-buffer of a pixel is simply the K smallest (depth, face) among its candidates - independent of the order the faces
+// arrive in - so the arrival order may be given up for parallelism:
+//   * lane = (pixel of the tile, quarter): the 16 pixels x 4 lanes each; the four lanes of a pixel take the tile's faces
+//     in turn and keep a K-list each (same LDS as the 8x8 kernel's 64 lists).  A wave's evaluation pass covers four
+//     faces, a face's bbox +- sqrt(blur) covers most of a 4x4 tile (it covered a third of an 8x8 one), and a tile's
+//     margin ring holds 2.25x fewer faces: ~9x fewer passes per tile, four times as many tiles to fill the chip with.
+//   * a face's nine floats come from the lane that loaded them in the tile test (cross-lane read) instead of a second,
+//     dependent memory read per surviving face.
+//   * the farthest entry of a full list is cached (depth, face, slot): a candidate that does not displace it costs one
+//     compare instead of a scan of the list; the scan runs only after a replacement.
+//   * at the end every lane sorts its list, finds the rank of each of its entries in the union of the pixel's four lists
+//     (three monotone cursors into the siblings' sorted lists) and writes the entries ranked below K - distance and
+//     barycentrics re-derived from the face, the same expressions on the same inputs as at arrival.
+// Bit-identical to occ_rast_naive_fwd_kernel on all four outputs (tests/test_gpu_rasterize_op.py).  Scenes with pairs
+// keep the 8x8 kernel above: the pair rule asks whether the sibling is in the list AT THE TIME the face arrives.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void occ_rast_quad_fwd_kernel(KbufArgs a, int tiles_x, int tiles_y) {
+    extern __shared__ unsigned char kb_smem[];
+    const int K = a.K, lane = threadIdx.x;
+    float* sz = reinterpret_cast<float*>(kb_smem);       // [K][64] depths, entry i of lane l at i * 64 + l
+    int* sf = reinterpret_cast<int*>(kb_smem) + 64 * K;  // [K][64] packed face indices
+    const int tpm = tiles_x * tiles_y;
+    const int n = blockIdx.x / tpm, t = blockIdx.x - n * tpm;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int pl = lane & 15, sub = lane >> 4;  // pixel of the tile, quarter
+    const int xi = tx * 4 + (pl & 3), yi = ty * 4 + (pl >> 2);
+    const bool valid = xi < a.W && yi < a.H;
+    const float yf = -1.0f + (2.0f * (float)(a.H - 1 - yi) + 1.0f) / (float)a.H;
+    const float xf = -1.0f + (2.0f * (float)(a.W - 1 - xi) + 1.0f) / (float)a.W;
+    const int xi1 = min(tx * 4 + 3, a.W - 1), yi1 = min(ty * 4 + 3, a.H - 1);
+    const float txmax = -1.0f + (2.0f * (float)(a.W - 1 - tx * 4) + 1.0f) / (float)a.W;
+    const float txmin = -1.0f + (2.0f * (float)(a.W - 1 - xi1) + 1.0f) / (float)a.W;
+    const float tymax = -1.0f + (2.0f * (float)(a.H - 1 - ty * 4) + 1.0f) / (float)a.H;
+    const float tymin = -1.0f + (2.0f * (float)(a.H - 1 - yi1) + 1.0f) / (float)a.H;
+    const float sqb = sqrtf(a.blur);
+    int qn = 0;
+    float zm = 0.f;  // farthest entry of the list once it is full: (depth, face) and its slot
+    int fm = 0, im = 0;
+    const int64_t f0 = a.first_idx[n], f1 = f0 + a.num_faces[n];
+    for (int64_t fc = f0; fc < f1; fc += 64) {
+        const int64_t fl = fc + lane;
+        bool hit = false;
+        KbufFace v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (fl < f1) {
+            v = kbuf_load(a.face_verts, fl);
+            const float area = k_edge(v.x0, v.y0, v.x1, v.y1, v.x2, v.y2);
+            hit = !(a.cull && area < 0.0f) && !(area <= kEpsilon && area >= -kEpsilon) && !(fmaxf(fmaxf(v.z0, v.z1), v.z2) < 0.0f);
+            const float xmin = fminf(fminf(v.x0, v.x1), v.x2) - sqb, xmax = fmaxf(fmaxf(v.x0, v.x1), v.x2) + sqb;
+            const float ymin = fminf(fminf(v.y0, v.y1), v.y2) - sqb, ymax = fmaxf(fmaxf(v.y0, v.y1), v.y2) + sqb;
+            hit = hit && xmin <= txmax && txmin <= xmax && ymin <= tymax && tymin <= ymax;
+        }
+        unsigned long long m = __ballot(hit);
+        while (m) {  // four surviving faces per pass, one per quarter
+            int bsel = -1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (m) {
+                    const int b = __builtin_ctzll(m);
+                    m &= m - 1;
+                    if (sub == q) bsel = b;
+                }
+            }
+            const int src = bsel < 0 ? lane : bsel;
+            KbufFace u;
+            u.x0 = __shfl(v.x0, src, 64); u.y0 = __shfl(v.y0, src, 64); u.z0 = __shfl(v.z0, src, 64);
+            u.x1 = __shfl(v.x1, src, 64); u.y1 = __shfl(v.y1, src, 64); u.z1 = __shfl(v.z1, src, 64);
+            u.x2 = __shfl(v.x2, src, 64); u.y2 = __shfl(v.y2, src, 64); u.z2 = __shfl(v.z2, src, 64);
+            if (bsel < 0 || !valid) continue;
+            const KbufHit h = kbuf_eval(u, xf, yf, sqb, a.blur, a.persp, a.clipb);
+            if (!h.ok) continue;
+            const int f = (int)(fc + bsel);
+            int slot = -1;
+            if (qn < K) {
+                slot = qn++;
+                if (qn == K) {  // the list has just filled up: find its farthest entry (this one included)
+                    sz[slot * 64 + lane] = h.pz;
+                    sf[slot * 64 + lane] = f;
+                    slot = -1;
+                    im = 0; zm = sz[lane]; fm = sf[lane];
+                    for (int i = 1; i < K; ++i) {
+                        const float zi = sz[i * 64 + lane];
+                        const int fi = sf[i * 64 + lane];
+                        if (zi > zm || (zi == zm && fi > fm)) { im = i; zm = zi; fm = fi; }
+                    }
+                }
+            } else if (h.pz < zm || (h.pz == zm && f < fm)) {
+                // full: the candidate displaces the farthest entry; the new farthest is found by one scan
+                sz[im * 64 + lane] = h.pz;
+                sf[im * 64 + lane] = f;
+                im = 0; zm = sz[lane]; fm = sf[lane];
+                for (int i = 1; i < K; ++i) {
+                    const float zi = sz[i * 64 + lane];
+                    const int fi = sf[i * 64 + lane];
+                    if (zi > zm || (zi == zm && fi > fm)) { im = i; zm = zi; fm = fi; }
+                }
+            }
+            if (slot >= 0) {
+                sz[slot * 64 + lane] = h.pz;
+                sf[slot * 64 + lane] = f;
+            }
+        }
+    }
+    // ascending (z, f): insertion sort of this lane's column
+    for (int i = 1; i < qn; ++i) {
+        const float zi = sz[i * 64 + lane];
+        const int fi = sf[i * 64 + lane];
+        int j = i - 1;
+        while (j >= 0) {
+            const float zj = sz[j * 64 + lane];
+            const int fj = sf[j * 64 + lane];
+            if (!(zj > zi || (zj == zi && fj > fi))) break;
+            sz[(j + 1) * 64 + lane] = zj;
+            sf[(j + 1) * 64 + lane] = fj;
+            --j;
+        }
+        sz[(j + 1) * 64 + lane] = zi;
+        sf[(j + 1) * 64 + lane] = fi;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // the pixel's four sorted lists -> one: rank of each own entry in the union (faces are distinct, so no ties)
+    const int l1 = pl + 16 * ((sub + 1) & 3), l2 = pl + 16 * ((sub + 2) & 3), l3 = pl + 16 * ((sub + 3) & 3);
+    const int n1 = __shfl(qn, l1, 64), n2 = __shfl(qn, l2, 64), n3 = __shfl(qn, l3, 64);
+    if (!valid) return;
+    const int total = min(K, qn + n1 + n2 + n3);
+    const long pix = ((long)n * a.H + yi) * a.W + xi;
+    int64_t* qf = a.p2f + pix * K;
+    float* qz = a.zbuf + pix * K;
+    float* qd = a.dists + pix * K;
+    float* qb = a.bary + pix * K * 3;
+    int p1 = 0, p2 = 0, p3 = 0;
+    auto less_than = [&](int l, int i, float z, int f) {  // entry i of lane l < (z, f)
+        const float zi = sz[i * 64 + l];
+        return zi < z || (zi == z && sf[i * 64 + l] < f);
+    };
+    for (int i = 0; i < qn; ++i) {
+        const float z = sz[i * 64 + lane];
+        const int f = sf[i * 64 + lane];
+        while (p1 < n1 && less_than(l1, p1, z, f)) ++p1;
+        while (p2 < n2 && less_than(l2, p2, z, f)) ++p2;
+        while (p3 < n3 && less_than(l3, p3, z, f)) ++p3;
+        const int rank = i + p1 + p2 + p3;
+        if (rank >= K) break;
+        const KbufHit h = kbuf_eval(kbuf_load(a.face_verts, f), xf, yf, sqb, a.blur, a.persp, a.clipb);
+        qf[rank] = f;
+        qz[rank] = z;
+        qd[rank] = h.inside ? -h.dist : h.dist;
+        qb[rank * 3] = h.c0; qb[rank * 3 + 1] = h.c1; qb[rank * 3 + 2] = h.c2;
+    }
+    for (int i = total + sub; i < K; i += 4) {
+        qf[i] = -1; qz[i] = -1.0f; qd[i] = -1.0f;
+        qb[i * 3] = qb[i * 3 + 1] = qb[i * 3 + 2] = -1.0f;
+    }
+}
+
 // dists part of RasterizeMeshesBackward: one thread per (pixel, k), atomicAdd into grad_face_verts
 __global__ __launch_bounds__(256) void occ_rast_naive_bwd_kernel(const float* __restrict__ face_verts,
                                                                  const int64_t* __restrict__ p2f,

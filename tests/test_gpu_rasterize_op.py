@@ -95,10 +95,11 @@ def test_sigmoid_alpha_blend_matches_torch_and_oracle(teapot):
 
 
 def test_tiled_kbuffer_is_bit_identical_to_the_naive_one(teapot):
-    """occ_rasterize_meshes_tiled (one wave per 8x8 tile, faces pre-filtered per tile, (depth, face) lists in LDS) against
+    """occ_rasterize_meshes_tiled (one wave per tile, faces pre-filtered per tile, (depth, face) lists in LDS; 4x4 tiles
+    with four faces in flight when there are no clipped pairs, 8x8 tiles in face order when there are) against
     occ_rasterize_meshes_naive (one thread per pixel over all faces): all four outputs bit for bit - two meshes, image
-    sides that are no multiple of 8, K = 1 / 8 / 100, the z-clipped scene with its clipped pairs, a 5 120-face mesh -
-    and faster where the tile filter has something to remove."""
+    sides that are no multiple of 8 (or 4), K = 1 / 8 / 100, the z-clipped scene with its clipped pairs, a 5 120-face
+    mesh - and faster, also on sub-pixel faces."""
     import time
 
     from occlusionenv_amd.meshes import SyntheticShapeNet
@@ -132,15 +133,20 @@ def test_tiled_kbuffer_is_bit_identical_to_the_naive_one(teapot):
     v, f = SyntheticShapeNet(n_models=1, seed=5).models[0]
     R, T = O.look_at_view_transform(torch.tensor([4.0]), torch.tensor([0.0]), torch.tensor([0.3]))
     big = O.world_to_ndc(v, R[0], T[0])[f].contiguous()
-    both(big, torch.tensor([0]), torch.tensor([big.shape[0]]), 128, O.BLUR_RADIUS, 100)
-    # speed: where faces are larger than a pixel (teapot at 256x256) the tile filter removes most of the evaluation work;
-    # on sub-pixel faces both kernels spend their time keeping the 100-entry lists of the few covered pixels
-    # (scripts/dbg/kbuf_time.py: teapot 1.0 vs 2.8 ms, the 5 120-face mesh 9-11 ms either way)
+    bargs = (big, torch.tensor([0]), torch.tensor([big.shape[0]]), 128, O.BLUR_RADIUS, 100)
+    both(*bargs)
+    both(big, torch.tensor([0]), torch.tensor([big.shape[0]]), (50, 38), O.BLUR_RADIUS, 100)  # sides that are no multiple of 4
+    both(torch.cat([big, big * torch.tensor([0.5, 0.5, 1.0])]), torch.tensor([0, big.shape[0]]), torch.tensor([big.shape[0]] * 2), 64, O.BLUR_RADIUS, 3)  # full lists everywhere
+    # speed (scripts/dbg/kbuf_time.py, round 4): teapot at 256x256 0.22 vs 2.8 ms; the 5 120-face mesh at 128x128 - a few
+    # hundred covered pixels with hundreds of candidates each - 1.2 vs 10.6 ms (round 3's 8x8 tiles in face order: 9-11 ms)
     args = (fv, torch.tensor([0]), torch.tensor([F1]), 256, O.BLUR_RADIUS, 100)
     both(*args)  # warm-up of both kernels
     t_tiled, t_naive = both(*args)
     print("teapot, 256x256, K=100: tiled %.2f ms, naive %.2f ms" % (t_tiled * 1e3, t_naive * 1e3))
     assert t_tiled < t_naive
+    t_tiled, t_naive = both(*bargs)
+    print("5 120 faces, 128x128, K=100: tiled %.2f ms, naive %.2f ms" % (t_tiled * 1e3, t_naive * 1e3))
+    assert t_tiled < 0.5 * t_naive
 
 
 def test_zbuf_and_bary_gradients_match_torch_autograd(teapot):
