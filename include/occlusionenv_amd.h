@@ -273,12 +273,12 @@ int occ_rasterize_meshes_naive(const float* face_verts, const int64_t* mesh_to_f
 /*
  * The same K-buffers, bit for bit, from a tiled kernel: one wave per (mesh, tile) looks only at the faces whose
  * bbox +- sqrt(blur) can reach a pixel centre of the tile and keeps the (depth, face) lists in LDS (F / faces-per-tile
- * times less evaluation work than the naive kernel; the producer callers of MeshRasterizer should use).  Without
- * clipped-face pairs (clipped_faces_neighbor_idx == NULL) a pixel's K-buffer is the K smallest (depth, face) of its
- * candidates whatever their arrival order: 4x4-pixel tiles, four faces in flight per wave, four partial lists per pixel
- * merged by rank at the end (round 4: 10.6 -> 1.2 ms for a 5 120-face mesh at 128x128, K = 100; the teapot at 256x256
- * 1.06 -> 0.22 ms).  With pairs: 8x8 tiles, faces in order.  Same arguments; faces_per_pixel above 128 (64 KiB of
- * lists) is served by the naive kernel.
+ * times less evaluation work than the naive kernel; the producer callers of MeshRasterizer should use).  For a mesh
+ * without clipped-face pairs (clipped_faces_neighbor_idx == NULL, or -1 for every face of the mesh: found out on the
+ * device, mesh by mesh) a pixel's K-buffer is the K smallest (depth, face) of its candidates whatever their arrival order:
+ * 4x4-pixel tiles, four faces in flight per wave, four partial lists per pixel merged by rank at the end (round 4:
+ * 10.6 -> 1.2 ms for a 5 120-face mesh at 128x128, K = 100; the teapot at 256x256 1.06 -> 0.22 ms).  A mesh with pairs:
+ * 8x8 tiles, faces in order.  Same arguments; faces_per_pixel above 128 (64 KiB of lists) is served by the naive kernel.
  */
 int occ_rasterize_meshes_tiled(const float* face_verts, const int64_t* mesh_to_face_first_idx,
                                const int64_t* num_faces_per_mesh, const int64_t* clipped_faces_neighbor_idx,

@@ -377,16 +377,16 @@ extern "C" int occ_rasterize_meshes_tiled(const float* face_verts, const int64_t
     KbufArgs a{face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, n_meshes, H, W,
                faces_per_pixel, blur_radius, perspective_correct, clip_barycentric_coords, cull_backfaces, pix_to_face,
                zbuf, bary, dists};
-    if (!clipped_faces_neighbor_idx) {
-        // no clipped-face pairs: the K-buffer does not depend on the arrival order - 4x4 tiles, four faces in flight
-        const int qx = (W + 3) / 4, qy = (H + 3) / 4;
-        hipLaunchKernelGGL(occ_rast_quad_fwd_kernel, dim3((unsigned)(n_meshes * qx * qy)), dim3(64), lds,
-                           (hipStream_t)stream, a, qx, qy);
-        return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
+    // meshes without clipped-face pairs (no neighbour array, or all -1 for the mesh): the K-buffer does not depend on the
+    // arrival order - 4x4 tiles, four faces in flight; meshes with pairs: 8x8 tiles, faces in order.  With an array both
+    // kernels are launched and every wave finds out first which of the two its mesh belongs to.
+    const int qx = (W + 3) / 4, qy = (H + 3) / 4;
+    hipLaunchKernelGGL(occ_rast_quad_fwd_kernel, dim3((unsigned)(n_meshes * qx * qy)), dim3(64), lds, (hipStream_t)stream, a, qx, qy);
+    if (clipped_faces_neighbor_idx) {
+        const int tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
+        hipLaunchKernelGGL(occ_rast_tiled_fwd_kernel, dim3((unsigned)(n_meshes * tiles_x * tiles_y)), dim3(64), lds,
+                           (hipStream_t)stream, a, tiles_x, tiles_y, 1);
     }
-    const int tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
-    hipLaunchKernelGGL(occ_rast_tiled_fwd_kernel, dim3((unsigned)(n_meshes * tiles_x * tiles_y)), dim3(64), lds,
-                       (hipStream_t)stream, a, tiles_x, tiles_y);
     return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
 }
 

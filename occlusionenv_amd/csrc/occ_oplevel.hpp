@@ -202,13 +202,30 @@ __device__ __forceinline__ KbufFace kbuf_load(const float* __restrict__ face_ver
     return KbufFace{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]};
 }
 
-__global__ __launch_bounds__(64) void occ_rast_tiled_fwd_kernel(KbufArgs a, int tiles_x, int tiles_y) {
+// Does mesh n hold a clipped-face pair?  (PyTorch3D's clip_faces hands the rasteriser a neighbour array whenever clipping is
+// enabled - all -1 unless a face straddled the clip plane - so "no array" is the rare case and "an array without pairs" the
+// common one.)  Every wave of the two tiled kernels asks this for its mesh first: a coalesced pass over the mesh's slice of
+// the array, a few microseconds; the kernel whose mode the mesh is not in returns at once.
+__device__ __forceinline__ bool mesh_has_pairs(const KbufArgs& a, int n, int lane) {
+    if (!a.neighbor) return false;
+    const int64_t f0 = a.first_idx[n], f1 = f0 + a.num_faces[n];
+    bool any = false;
+    for (int64_t fc = f0; fc < f1; fc += 64) {
+        const int64_t fl = fc + lane;
+        any = any || (fl < f1 && a.neighbor[fl] != -1);
+    }
+    return __ballot(any) != 0ull;
+}
+
+// (ordered_only_with_pairs: the order-free kernel below was launched as well and takes the meshes without pairs)
+__global__ __launch_bounds__(64) void occ_rast_tiled_fwd_kernel(KbufArgs a, int tiles_x, int tiles_y, int ordered_only_with_pairs) {
     extern __shared__ unsigned char kb_smem[];
     const int K = a.K, lane = threadIdx.x;
     float* sz = reinterpret_cast<float*>(kb_smem);            // [K][64] depths
     int* sf = reinterpret_cast<int*>(kb_smem) + 64 * K;       // [K][64] packed face indices
     const int tpm = tiles_x * tiles_y;
     const int n = blockIdx.x / tpm, t = blockIdx.x - n * tpm;
+    if (ordered_only_with_pairs && !mesh_has_pairs(a, n, lane)) return;
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
     const int xi = tx * 8 + (lane & 7), yi = ty * 8 + (lane >> 3);
     const bool valid = xi < a.W && yi < a.H;
@@ -319,7 +336,8 @@ __global__ __launch_bounds__(64) void occ_rast_tiled_fwd_kernel(KbufArgs a, int 
 
 // ------------------------------------------------------------------------------------------
 // Sub-pixel meshes (round 4): occ_rast_quad_fwd_kernel - one wave per (mesh, 4x4-pixel tile), FOUR faces in flight.
-// Without clipped-face pairs (clipped_faces_neighbor_idx == NULL: the case of every scene the camera is not inside) the
+// Without clipped-face pairs (no neighbour array, or one that is -1 for every face of the mesh - mesh_has_pairs above: the
+// case of every mesh the camera is not inside) the
 // K-buffer of a pixel is simply the K smallest (depth, face) among its candidates - independent of the order the faces
 // arrive in - so the arrival order may be given up for parallelism:
 //   * lane = (pixel of the tile, quarter): the 16 pixels x 4 lanes each; the four lanes of a pixel take the tile's faces
@@ -333,7 +351,7 @@ __global__ __launch_bounds__(64) void occ_rast_tiled_fwd_kernel(KbufArgs a, int 
 //   * at the end every lane sorts its list, finds the rank of each of its entries in the union of the pixel's four lists
 //     (three monotone cursors into the siblings' sorted lists) and writes the entries ranked below K - distance and
 //     barycentrics re-derived from the face, the same expressions on the same inputs as at arrival.
-// Bit-identical to occ_rast_naive_fwd_kernel on all four outputs (tests/test_gpu_rasterize_op.py).  Scenes with pairs
+// Bit-identical to occ_rast_naive_fwd_kernel on all four outputs (tests/test_gpu_rasterize_op.py).  Meshes with pairs
 // keep the 8x8 kernel above: the pair rule asks whether the sibling is in the list AT THE TIME the face arrives.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void occ_rast_quad_fwd_kernel(KbufArgs a, int tiles_x, int tiles_y) {
@@ -343,6 +361,7 @@ __global__ __launch_bounds__(64) void occ_rast_quad_fwd_kernel(KbufArgs a, int t
     int* sf = reinterpret_cast<int*>(kb_smem) + 64 * K;  // [K][64] packed face indices
     const int tpm = tiles_x * tiles_y;
     const int n = blockIdx.x / tpm, t = blockIdx.x - n * tpm;
+    if (mesh_has_pairs(a, n, lane)) return;  // the ordered 8x8 kernel takes this mesh
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
     const int pl = lane & 15, sub = lane >> 4;  // pixel of the tile, quarter
     const int xi = tx * 4 + (pl & 3), yi = ty * 4 + (pl >> 2);

@@ -135,6 +135,12 @@ def test_tiled_kbuffer_is_bit_identical_to_the_naive_one(teapot):
     big = O.world_to_ndc(v, R[0], T[0])[f].contiguous()
     bargs = (big, torch.tensor([0]), torch.tensor([big.shape[0]]), 128, O.BLUR_RADIUS, 100)
     both(*bargs)
+    # a neighbour array without pairs (what clip_faces hands over for a scene nothing was clipped in): still the order-free
+    # kernel, found out per mesh on the device; and a call with one mesh of either kind
+    both(big, torch.tensor([0]), torch.tensor([big.shape[0]]), 96, O.BLUR_RADIUS, 100, torch.full((big.shape[0],), -1, dtype=torch.int64))
+    sq = fvc * torch.tensor([0.25, 0.25, 1.0])
+    both(torch.cat([sq, big]), torch.tensor([0, sq.shape[0]]), torch.tensor([sq.shape[0], big.shape[0]]), 64, O.BLUR_RADIUS, 20,
+         torch.cat([nb, torch.full((big.shape[0],), -1, dtype=torch.int64)]))
     both(big, torch.tensor([0]), torch.tensor([big.shape[0]]), (50, 38), O.BLUR_RADIUS, 100)  # sides that are no multiple of 4
     both(torch.cat([big, big * torch.tensor([0.5, 0.5, 1.0])]), torch.tensor([0, big.shape[0]]), torch.tensor([big.shape[0]] * 2), 64, O.BLUR_RADIUS, 3)  # full lists everywhere
     # speed (scripts/dbg/kbuf_time.py, round 4): teapot at 256x256 0.22 vs 2.8 ms; the 5 120-face mesh at 128x128 - a few
@@ -249,7 +255,8 @@ def test_order_free_kbuffer_equals_the_naive_one_on_random_scenes():
         size = [(64, 64), (50, 38), (97, 61), (128, 128), (33, 70)][case % 5]
         blur = O.BLUR_RADIUS * (1.0, 4.0, 0.0)[case % 3]
         cull, clipb = case % 4 != 3, blur > 0 and case % 5 != 4
-        args = (fv, torch.tensor(first), torch.tensor(num), size, blur, K, True, clipb, cull)
+        nbr = torch.full((fv.shape[0],), -1, dtype=torch.int64, device="cuda") if case % 2 else None  # clip_faces' array for an unclipped scene
+        args = (fv, torch.tensor(first), torch.tensor(num), size, blur, K, True, clipb, cull, nbr)
         a = rasterize_meshes(*args, naive=False)
         b = rasterize_meshes(*args, naive=True)
         for x, y, name in zip(a, b, ("pix_to_face", "zbuf", "bary", "dists")):
