@@ -105,15 +105,18 @@ def test_tiled_kbuffer_is_bit_identical_to_the_naive_one(teapot):
     from occlusionenv_amd.meshes import SyntheticShapeNet
     from occlusionenv_amd.ops import rasterize_meshes
 
-    def both(fv, first, num, size, blur, K, nb=None, covered=True):
+    def both(fv, first, num, size, blur, K, nb=None, covered=True, reps=1):
         args = (fv.cuda(), first, num, size, blur, K, True, blur > 0, True, None if nb is None else nb.cuda())
         out = []
         for naive in (False, True):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            r = rasterize_meshes(*args, naive=naive)
-            torch.cuda.synchronize()
-            out.append((r, time.perf_counter() - t0))
+            best = float("inf")
+            for _ in range(reps):  # (timed calls: the best of a few - a call may have to wait for the allocator)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r = rasterize_meshes(*args, naive=naive)
+                torch.cuda.synchronize()
+                best = min(best, time.perf_counter() - t0)
+            out.append((r, best))
         for a, b, name in zip(out[0][0], out[1][0], ("pix_to_face", "zbuf", "bary", "dists")):
             assert torch.equal(a, b), (name, size, K)
         assert not covered or int((out[0][0][0] >= 0).sum()) > 0
@@ -147,10 +150,10 @@ def test_tiled_kbuffer_is_bit_identical_to_the_naive_one(teapot):
     # hundred covered pixels with hundreds of candidates each - 1.2 vs 10.6 ms (round 3's 8x8 tiles in face order: 9-11 ms)
     args = (fv, torch.tensor([0]), torch.tensor([F1]), 256, O.BLUR_RADIUS, 100)
     both(*args)  # warm-up of both kernels
-    t_tiled, t_naive = both(*args)
+    t_tiled, t_naive = both(*args, reps=3)
     print("teapot, 256x256, K=100: tiled %.2f ms, naive %.2f ms" % (t_tiled * 1e3, t_naive * 1e3))
     assert t_tiled < t_naive
-    t_tiled, t_naive = both(*bargs)
+    t_tiled, t_naive = both(*bargs, reps=3)
     print("5 120 faces, 128x128, K=100: tiled %.2f ms, naive %.2f ms" % (t_tiled * 1e3, t_naive * 1e3))
     assert t_tiled < 0.5 * t_naive
 
