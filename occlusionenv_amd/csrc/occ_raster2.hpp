@@ -865,7 +865,9 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                                         make_uint2(key, (uint32_t)pix | (uint32_t)(fseq_base + f) << 6);
                                     // (the payload is read back for the kept entries only; writing it with the non-temporal hint:
                                     // 1.990 vs 1.992 ms, nothing - round 4)
+#ifndef OCC_DBG2_NO_PAY  // timing experiment only: what the payload's 12 bytes per candidate cost (results are void)
                                     *reinterpret_cast<LogPay*>(reinterpret_cast<char*>(lg.pay) + __umul24(e, 12u)) = LogPay{c1.q, c1.ge, c1.ga};
+#endif
                                 }
                             }
 #endif
