@@ -51,12 +51,21 @@ def parse_args(argv=None):
                     help="gloo = rehearsal of the N>1 path on fewer GPUs than ranks (ranks share devices)")
     ap.add_argument("--cpu-sample", type=int, default=16)
     ap.add_argument("--pool-models", type=int, default=1024, help="synthetic mesh pool size (SURVEY 8d: 1024, seed 1234)")
-    ap.add_argument("--rollout-T", type=int, default=50, help="ppo_rollout: steps per update (trainRL.py:24,46)")
+    ap.add_argument("--rollout-T", type=int, default=50,
+                    help="ppo_rollout: steps between policy updates.  Default 50 = BASELINE config 5's rollout length (SURVEY 8d: "
+                         "'PPO-style rollout T=50' = one episode of max_ep_len steps, trainRL.py:22); the reference's own cadence is "
+                         "--rollout-T 200 (update_timestep = max_ep_len * 4, trainRL.py:46)")
     ap.add_argument("--ppo-epochs", type=int, default=80, help="ppo_rollout: K_epochs (trainRL.py:49)")
     ap.add_argument("--max-ep-len", type=int, default=50, help="ppo_rollout: episode time limit (trainRL.py:22), 0 = none")
-    ap.add_argument("--output-ring", type=int, default=3,
-                    help="persistent output sets used in turn (the step's obs / full_state are overwritten that many steps "
-                         "later; the combine kernel then writes only what changed); 0 = freshly allocated outputs every step")
+    ap.add_argument("--output-ring", type=int, default=0,
+                    help="opt-in: k >= 2 persistent output sets used in turn (the step's obs / full_state are OVERWRITTEN k steps "
+                         "later whoever holds them - not the reference's tensor lifetime).  Default 0: recycled outputs, "
+                         "SimpleVecEnv's default - a set is reused only once no view of it is alive, so no caller can see a "
+                         "tensor change (reference semantics)")
+    ap.add_argument("--no-recycle", action="store_true",
+                    help="every step allocates its obs / full_state (and writes every pixel of them) instead of recycling "
+                         "released output sets; the 'fresh_outputs' leg of the JSON line measures this mode as well")
+    ap.add_argument("--fresh-steps", type=int, default=40, help="steps of the fresh_outputs leg (N = 1 only; 0 = skip)")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
     args = ap.parse_args(argv)
     if args.envs is None:
@@ -310,6 +319,8 @@ def main(argv=None):
     scene_workload = "shapenet5k" if ppo_mode else args.workload
     venv, ds = build_env(scene_workload, args.envs, args.img, seed=42 + rank, pool_models=args.pool_models)
     eng = venv.engine
+    if args.no_recycle:
+        venv.use_recycled_outputs(0)
     if args.output_ring and eng.R:
         venv.use_output_ring(args.output_ring)
     # SURVEY.md §8d scene distribution: x2 ~ N(0,1) (np.random, seeded), az ~ U(-0.6, 0.6), el = 0; scenes pass
@@ -411,6 +422,24 @@ def main(argv=None):
     lib.occ_profile_enable(0)
     eng.check_status()
     assert torch.isfinite(g).all()
+    # fresh_outputs leg (N = 1): the same step with every output tensor allocated anew and written in full - what the
+    # reference's allocator does - timed after the main region on the same env, for the reader who wants that number
+    fresh = None
+    if world == 1 and args.fresh_steps > 0 and not ppo_mode and eng.R and (not args.no_recycle or args.output_ring):
+        del g
+        venv.use_output_ring(0)
+        venv.use_recycled_outputs(0)
+        for _ in range(3):
+            one_step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.fresh_steps):
+            one_step()
+        barrier()
+        dtf = time.perf_counter() - t1
+        fresh = {"value": args.envs * args.fresh_steps / dtf, "unit": "env-steps/s", "ms_per_step": dtf / args.fresh_steps * 1e3,
+                 "steps": args.fresh_steps,
+                 "mode": "every step allocates obs / full_state and the combine kernel writes every pixel (no recycling, no ring)"}
     if world > 1:
         tmax = torch.tensor([dt], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -452,9 +481,16 @@ def main(argv=None):
         # env-step - 28 B x K x S^2 per soft render x 3 + 28 B x S^2 hard forward, 12 B x K x S^2 x 3 re-read backward
         frag_step = (28.0 * 100 * 3 + 28.0 + 12.0 * 100 * 3) * args.img * args.img
         ring_on = bool(args.output_ring and eng.R)
+        recycle_on = bool(eng.R and not args.no_recycle and not ring_on)
+        out_mode = (f"outputs in a ring of {args.output_ring} persistent sets (overwritten {args.output_ring} steps later)" if ring_on else
+                    "recycled outputs (a released output set is reused; nothing a caller holds is ever overwritten)" if recycle_on else
+                    "fresh output tensors every step")
+        ms_step = dt / args.steps * 1e3
+        step_frac = b_launch / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS
         out = {
             # BASELINE.json's metric is quoted at 128x128 (the default --img); other sizes say so
-            "metric": f"env steps/sec (batched renders) @{args.img}x{args.img}, {meshes}",
+            "metric": f"env steps/sec (batched renders) @{args.img}x{args.img}, {meshes}"
+                      + (f", outputs in an overwriting ring of {args.output_ring}" if ring_on else ""),
             "value": value,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -470,13 +506,18 @@ def main(argv=None):
                                    f"3 objects/env drawn from a pool of {args.pool_models if ds is not None else 1} meshes "
                                    f"(seed 1234), K=100 soft x3 + hard RGB-D, forward + action gradient"
                                    + (f", + {collective} all-gather of 1044-B rollout records" if world > 1 else "")
-                                   + (f"; outputs in a ring of {args.output_ring} persistent sets" if ring_on else "; fresh output tensors every step"),
+                                   + "; " + out_mode,
                        "envs_per_gpu": args.envs, "img": args.img, "faces_per_pixel": 100, "pool_models": args.pool_models,
-                       "output_ring": args.output_ring if ring_on else 0, "collective_backend": args.dist_backend if world > 1 else None,
+                       "output_ring": args.output_ring if ring_on else 0, "recycled_outputs": recycle_on, "collective_backend": args.dist_backend if world > 1 else None,
                        "sharding": f"env-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": raster_name, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                         # the same algorithmic bytes over the WHOLE step (all launches, host gaps) / peak
+                         "step_frac": step_frac,
+                         # what the counters say the dominant kernel really moves (2 FETCH + WRITE) / its duration / peak
+                         "counter_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and launches.value) else None,
+                         "traffic": traffic,
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": b_launch, "avg_launch_ms": avg_ms,
                          "launches": launches.value, "valu": valu,
@@ -487,6 +528,8 @@ def main(argv=None):
                                        "unit": "GB/s", "frac": (frag_step * args.envs / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if launches.value else None},
                          "note": "VALU/latency-bound rasterisation; compulsory bytes are ~1.47 MB/env-step (SURVEY 8d)"},
         }
+        if fresh is not None:
+            out["fresh_outputs"] = fresh
         if ppo_mode:
             out["ppo"] = {"updates": ppo_state["updates"], "T": args.rollout_T, "epochs": args.ppo_epochs,
                           "last_update": ppo_state["stats"]}

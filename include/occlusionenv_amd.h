@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define OCC_ABI_VERSION 8
+#define OCC_ABI_VERSION 9
 
 /* return codes */
 #define OCC_OK 0
@@ -423,12 +423,25 @@ typedef struct OccAutoResetOpts {
     /* (n_reserve,S,S,4): receives the stored occlusion image of every slot taken in this call (what the reference's
      * env.image holds after reset(), environment.py:319). */
     float* reset_full_state;
+    /* normWithObjectSize (environment.py:208,320,324): norm_flags (n_env) int32, nonzero = that env divides its reward by
+     * objectMass = sum_px (a1 + a2 + a3)^2 + 1 of its reset render instead of loss + 1; slot_objsum (n_reserve) holds that
+     * sum for the stored render of every reserve slot (occ_object_mass).  Both NULL: loss + 1 for every env. */
+    const int32_t* norm_flags;
+    const float* slot_objsum;
 } OccAutoResetOpts;
 
 int occ_auto_reset(const uint8_t* done, const float* loss_all, const int32_t* status, int n_env, int n_reserve,
                    int32_t* rs_state, int32_t* rs_tries, const OccEnvState* st, float* obs_all, const float* full_state_all,
                    const OccReserveStore* store, float* term_obs, int img, int32_t* pairs, int32_t* report,
                    const OccAutoResetOpts* opts, void* stream);
+
+/*
+ * objectMass of reset() with normWithObjectSize (environment.py:320,324: self.objects = image1 + image2 + image3;
+ * objectMass = sum(objects[..., 3] ** 2) + 1): out[r] = sum over the pixels of (a1 + a2 + a3)^2 for rows r of
+ * alphas (n_rows,3,S,S), in a fixed summation order.  gate (n_rows) int32 or NULL: only rows with gate[r] == gate_value
+ * are computed, the others keep what out holds (the reserve: rows rendered in this step are the OCC_RS_PENDING ones).
+ */
+int occ_object_mass(const float* alphas, int n_rows, int img, const int32_t* gate, int gate_value, float* out, void* stream);
 
 /*
  * Host -> reserve: n packed rows of 13 words (slot, mesh id x3, offset x9 as float bits) already in device

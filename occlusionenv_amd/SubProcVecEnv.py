@@ -29,6 +29,8 @@ from .baseVecEnv import VecEnv
 from .engine import OcclusionEngine
 from .environment import shared_pool
 
+RECYCLE_SETS = 4  # persistent output sets of the recycled-outputs pool (engine.OcclusionEngine.output_recycle)
+
 
 def _structure(space):
     """How a gym-style space is laid out, told by duck-typing (gym itself may be absent): a mapping of named
@@ -119,7 +121,12 @@ class SimpleVecEnv(VecEnv):
         False and ``infos[i]["TimeLimit.truncated"] = True`` beside ``terminal_observation``.
 
         ``venv.use_output_ring(k)`` (k >= 2): the engine's output ring (engine.OcclusionEngine): ``obs`` /
-        ``infos[i]["full_state"]`` of a step are views of one of k persistent output sets and are overwritten k steps later."""
+        ``infos[i]["full_state"]`` of a step are views of one of k persistent output sets and are overwritten k steps later.
+
+        On by default (batched path with a reserve): RECYCLED OUTPUTS - the tensors of a step come from a small pool of
+        persistent output sets, and a set is reused only once no view of it is alive anywhere (the caller dropped that
+        step's ``obs`` / ``infos``).  What a caller holds is never overwritten, exactly as with the reference's fresh
+        tensors per step (SubProcVecEnv.py:215-219); ``venv.use_recycled_outputs(0)`` switches to plain allocations."""
         self.envs = [fn() for fn in env_fns]
         env = self.envs[0]
         VecEnv.__init__(self, len(env_fns), env.observation_space, env.action_space)
@@ -135,7 +142,8 @@ class SimpleVecEnv(VecEnv):
         # reserve from running dry (with N/8 the time-limited PPO rollout fell back to reading the report at the end of
         # most steps: 3.31 instead of 2.87 ms per step at 256 envs)
         reserve = min(512, self.num_envs // 4) if (same_data and self.num_envs >= 16) else 0
-        self.engine = OcclusionEngine(shared_pool(dev), self.num_envs, env.img_size, device=dev, reserve=reserve)
+        self.engine = OcclusionEngine(shared_pool(dev), self.num_envs, env.img_size, device=dev, reserve=reserve,
+                                      output_recycle=RECYCLE_SETS if reserve else 0)
         self._age_host = np.zeros(self.num_envs, dtype=np.int64)  # the time limit's counters of the host-driven path (no reserve)
         self.max_ep_len = None
         for i, e in enumerate(self.envs):
@@ -152,9 +160,10 @@ class SimpleVecEnv(VecEnv):
         # optional torch.cuda.Event: recorded by an asynchronous consumer of the last step's ``obs`` (another stream)
         # once it has read it; the in-place reset fallback below waits on it before overwriting rows of ``obs``
         self.obs_consumer_event = None
-        # output ring: the consumer event of the step that last used each output set (a set is not overwritten before
-        # the side stream that still reads it - RecordExchange packs step k's records while step k + 1 renders - is done)
-        self._ring_events, self._ring_last = None, None
+        # output ring / recycled outputs: every output set remembers the consumer event of the step that last used it (a
+        # set is not overwritten before the side stream that still reads it - RecordExchange packs step k's records while
+        # step k + 1 renders - is done); _last_set = the set of the previous step
+        self._last_set = None
 
     def step_async(self, actions):
         self.actions = actions
@@ -168,8 +177,20 @@ class SimpleVecEnv(VecEnv):
             raise ValueError("the output ring needs the batched step path with a reserve (>= 16 envs on one dataset)")
         if k == 1 or k < 0:
             raise ValueError("output ring: 0 (fresh outputs) or k >= 2 sets")
-        eng.output_ring, eng._ring, eng._ring_pos = int(k), None, 0
-        self._ring_events, self._ring_last = None, None
+        eng.output_ring, eng._ring, eng._ring_pos, eng._picked = int(k), None, 0, None
+        self._last_set = None
+
+    def use_recycled_outputs(self, max_sets: int = 4) -> None:
+        """Recycled outputs (class docstring) with at most ``max_sets`` persistent output sets; 0 = every step allocates
+        its tensors (and the combine kernel writes every pixel of them)."""
+        self._drain()
+        eng = self.engine
+        if max_sets < 0:
+            raise ValueError("max_sets must be >= 0")
+        eng.output_recycle, eng._picked = (int(max_sets) if eng.R else 0), None
+        if not eng.output_ring:
+            eng._ring = None
+        self._last_set = None
 
     def stagger_ages(self, seed=None) -> None:
         """Spread the envs' episode ages uniformly over [0, max_ep_len): envs that were reset together would otherwise
@@ -331,16 +352,13 @@ class SimpleVecEnv(VecEnv):
                 self._warm_reserve()
             # the report of the previous step is read as late as possible: after this step's outputs are allocated
             # and its launch arguments are built, right before its first kernel launch
-            if eng.output_ring:
-                if self._ring_events is None or len(self._ring_events) != eng.output_ring:
-                    self._ring_events, self._ring_last = [None] * eng.output_ring, None
-                if self._ring_last is not None:  # what the caller attached after the previous step belongs to ITS set
-                    self._ring_events[self._ring_last] = self.obs_consumer_event
-                slot = eng._ring_pos  # the set this step writes
-                if self._ring_events[slot] is not None:
-                    torch.cuda.current_stream(eng.device).wait_event(self._ring_events[slot])
-                    self._ring_events[slot] = None
-                self._ring_last = slot
+            if self._last_set is not None:  # what the caller attached after the previous step belongs to ITS set
+                self._last_set["event"] = self.obs_consumer_event
+            _, oset = eng.pick_output_set()  # the set this step writes (None: freshly allocated tensors)
+            if oset is not None and oset["event"] is not None:
+                torch.cuda.current_stream(eng.device).wait_event(oset["event"])
+                oset["event"] = None
+            self._last_set = oset
             empty = []
 
             def pre_launch():  # the GPU idles from the report's arrival to this step's first launch: only what must precede it

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OCC_HIP_LIB") or os.path.join(_HERE, "libocc_hip.so")
 
 # layout constants (must match include/occlusionenv_amd.h)
-ABI_VERSION = 8
+ABI_VERSION = 9
 CAM_STRIDE = 48
 REC_STRIDE = 32
 TILE = 8
@@ -127,7 +127,7 @@ class OccCameraArgs(C.Structure):
 
 class OccAutoResetOpts(C.Structure):
     _fields_ = [("age", C.c_void_p), ("max_ep_len", C.c_int32), ("rect", C.c_void_p), ("arect", C.c_void_p),
-                ("reset_full_state", C.c_void_p)]
+                ("reset_full_state", C.c_void_p), ("norm_flags", C.c_void_p), ("slot_objsum", C.c_void_p)]
 
 
 class OccEnvState(C.Structure):
@@ -183,6 +183,7 @@ SYMBOLS = {
     "occ_auto_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.POINTER(OccEnvState), C.c_void_p, C.c_void_p, C.POINTER(OccReserveStore), C.c_void_p,
                                  C.c_int, C.c_void_p, C.c_void_p, C.POINTER(OccAutoResetOpts), C.c_void_p]),
+    "occ_object_mass": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "occ_reserve_refill": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
     "occ_profile_enable": (C.c_int, [C.c_int]),

@@ -529,11 +529,19 @@ extern "C" int occ_auto_reset(const uint8_t* done, const float* loss_all, const 
     OccAutoResetOpts o{};
     if (opts) o = *opts;
     if (o.max_ep_len > 0 && !o.age) return OCC_ERR_ARG;
+    if (o.norm_flags && !o.slot_objsum) return OCC_ERR_ARG;
     PairArgs pa{done, loss_all, status, n_env, n_reserve, rs_state, rs_tries, pairs, report, store->skip, o.age, o.max_ep_len};
     hipLaunchKernelGGL(occ_pair_kernel, dim3(1), dim3(1024), 0, s, pa);
     AutoCommitArgs ca{pairs, *st, obs_all, term_obs, store->obs, store->loss, img, n_env, o.age, o.rect, o.arect,
-                      store->full_state, o.reset_full_state};
+                      store->full_state, o.reset_full_state, o.norm_flags, o.slot_objsum};
     hipLaunchKernelGGL(occ_auto_commit_kernel, dim3(n_reserve, 1 + commit_obs_blocks(img) + commit_alpha_blocks(img)), dim3(256), 0, s, ca);
+    return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
+}
+
+extern "C" int occ_object_mass(const float* alphas, int n_rows, int img, const int32_t* gate, int gate_value, float* out,
+                               void* stream) {
+    if (!alphas || !out || n_rows <= 0 || img <= 0) return OCC_ERR_ARG;
+    hipLaunchKernelGGL(occ_object_mass_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, alphas, img, gate, gate_value, out);
     return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
 }
 

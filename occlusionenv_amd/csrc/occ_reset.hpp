@@ -135,6 +135,7 @@ struct AutoCommitArgs {
     int* age;                  // (n_env) or null: zeroed for the env that takes a slot
     int* rect; int* arect;     // region-tracking rects of obs_all / the alphas state or null: the committed row is a full frame
     const float* res_fs; float* reset_fs;  // stored occlusion image of the slot -> reset_fs[slot] (the env's image after reset) or null
+    const int* norm_flags; const float* slot_objsum;  // normWithObjectSize (environment.py:324) or null
 };
 // grid.y = 1 (state) + obs_blocks + alpha_blocks: the copies are sized by the image - a block moves ~4 x 256 float4 per
 // plane it touches (with the 8 + 6 blocks that were enough at 128 x 128 the commit of ONE env took 40 us at 256 x 256,
@@ -155,7 +156,9 @@ __global__ __launch_bounds__(256) void occ_auto_commit_kernel(AutoCommitArgs a) 
             a.st.radius[dst] = a.st.radius[src];
             const float l = a.res_loss[src - a.n_env];
             a.st.full_reward[dst] = l;
-            a.st.object_mass[dst] = l + 1.0f;
+            // environment.py:324: objectMass = sum(objects^2) + 1 if normWithObjectSize else loss + 1
+            const bool norm = a.norm_flags && a.norm_flags[dst] != 0;
+            a.st.object_mass[dst] = (norm ? a.slot_objsum[src - a.n_env] : l) + 1.0f;
         }
         if (tid < 3) {
             a.st.campos[dst * 3 + tid] = 0.f;
@@ -187,6 +190,26 @@ __global__ __launch_bounds__(256) void occ_auto_commit_kernel(AutoCommitArgs a) 
         float4* d4 = reinterpret_cast<float4*>(a.st.alphas + (size_t)dst * 3 * S2);
         for (size_t i = (size_t)(y - 1 - obs_blocks) * 256 + tid; i < 3 * S2 / 4; i += (size_t)alpha_blocks * 256) d4[i] = s4[i];
     }
+}
+
+// sum_px (a1 + a2 + a3)^2 of one row of alphas (3,S,S) per block: thread partials in pixel order, DPP wave sums, the four
+// waves' sums added in wave order (environment.py:320,324)
+__global__ __launch_bounds__(256) void occ_object_mass_kernel(const float* __restrict__ alphas, int img, const int* __restrict__ gate,
+                                                              int gate_value, float* __restrict__ out) {
+    __shared__ float s_w[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    if (gate && gate[r] != gate_value) return;
+    const size_t S2 = (size_t)img * img;
+    const float* a = alphas + (size_t)r * 3 * S2;
+    float acc = 0.f;
+    for (size_t i = tid; i < S2; i += 256) {
+        const float o = a[i] + a[S2 + i] + a[2 * S2 + i];
+        acc += o * o;
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) s_w[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) out[r] = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
 }
 
 __global__ __launch_bounds__(64) void occ_refill_kernel(const int* __restrict__ packed, int n, int n_env, int n_res,

@@ -48,7 +48,8 @@ class OcclusionEngine:
     """State + workspace of N environments on one GPU."""
 
     def __init__(self, pool: MeshPool, n_env: int, img_size: int, device=None, faces_per_pixel: int = 100,
-                 waves_per_cu: Optional[int] = None, reserve: int = 0, cost_order: bool = True, output_ring: int = 0):
+                 waves_per_cu: Optional[int] = None, reserve: int = 0, cost_order: bool = True, output_ring: int = 0,
+                 output_recycle: int = 0):
         self.lib = nat.load()
         if not torch.cuda.is_available():
             raise nat.NativeError("OcclusionEngine needs a ROCm GPU (torch.cuda.is_available() is False); "
@@ -76,6 +77,18 @@ class OcclusionEngine:
             raise ValueError("output_ring must be 0 (fresh outputs) or >= 2")
         self.output_ring = int(output_ring)
         self._ring, self._ring_pos = None, 0
+        # RECYCLED OUTPUTS (whole-batch steps with the reserve; what SimpleVecEnv switches on by default).  Up to
+        # ``output_recycle`` persistent output sets, like the ring - but a set is handed out again only once NOTHING outside
+        # the engine refers to its tensors any more (no live view of its obs / full_state storage: the caller dropped the
+        # step's ``obs`` and ``infos``, as a rollout loop does by rebinding them).  While somebody still holds them a step
+        # takes another free set, a new one, or - at the cap - freshly allocated tensors.  Nobody can therefore see a
+        # tensor change under them: the lifetime contract is the reference's (every step returns tensors of its own,
+        # /root/reference/SubProcVecEnv.py:215-219), only the allocator differs, and with it what the combine kernel has
+        # to write (the set still holds its background outside the tracked rects).
+        if output_recycle < 0:
+            raise ValueError("output_recycle must be >= 0 (0 = off)")
+        self.output_recycle = int(output_recycle)
+        self._picked = None  # the output set chosen for the next whole-batch step (pick_output_set), or "fresh"
         # the setup kernel stages every object's vertices in LDS once (False: three global gathers per face; same results)
         self.setup_vertex_lds = bool(int(os.environ.get("OCC_SETUP_VERTEX_LDS", "1")))
         d = self.device
@@ -104,6 +117,10 @@ class OcclusionEngine:
         # occ_auto_reset; max_ep_len = 0: no limit (the reference's SimpleVecEnv has none)
         self.age = torch.zeros(N, dtype=torch.int32, device=d)
         self.max_ep_len = 0
+        # normWithObjectSize (environment.py:208,320,324), per env: reset() then sets objectMass = sum_px (a1+a2+a3)^2 + 1
+        # instead of loss + 1.  Off for every env by default, like the reference; nothing is computed while none has it on.
+        self.norm_flags = torch.zeros(N, dtype=torch.int32, device=d)
+        self._norm_host = np.zeros(N, dtype=bool)
         # region tracking of the persistent alphas state (OccRenderOut.arect_prev / arect_next): outside rect[e] the
         # alphas of row e are zero.  Two arrays, flipped by every tracked launch; untracked writers mark rows full-frame.
         self._arect = [torch.tensor([self.S, self.S, -1, -1], dtype=torch.int32, device=d).repeat(NT, 1).contiguous()
@@ -147,8 +164,32 @@ class OcclusionEngine:
             self._res_obs = torch.zeros(self.R, 4, S, S, **f32)
             self._res_fs = torch.zeros(self.R, S, S, 4, **f32)
             self._res_loss = torch.zeros(self.R, **f32)
+            self._res_objsum = torch.zeros(self.R, **f32)  # sum_px (a1+a2+a3)^2 of every slot's stored render (normWithObjectSize)
             self._skip = torch.zeros(NT, **i32)
             self._skip[N:] = 1  # EMPTY slots are not rendered
+
+    # ---- normWithObjectSize ----------------------------------------------------------------
+    def set_norm_with_object_size(self, env_id: int, on: bool) -> None:
+        on = bool(on)
+        if self._norm_host[env_id] != on:
+            self._norm_host[env_id] = on
+            self.norm_flags[env_id] = int(on)
+
+    def _object_sum(self, alphas: torch.Tensor, gate=None, gate_value=0, out=None) -> torch.Tensor:
+        """sum_px (a1 + a2 + a3)^2 per row of ``alphas`` (n,3,S,S) (environment.py:320,324; occ_object_mass)."""
+        a = alphas.contiguous()
+        n = a.shape[0]
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, device=self.device)
+        nat.check(self.lib.occ_object_mass(_p(a), n, self.S, _p(gate), int(gate_value), _p(out), self._stream()), "occ_object_mass")
+        return out
+
+    def _reset_mass(self, loss: torch.Tensor, alphas: torch.Tensor, env_ids) -> torch.Tensor:
+        """objectMass of reset() for the envs ``env_ids`` (tensor of indices or None = all), environment.py:324."""
+        if not self._norm_host.any():
+            return loss + 1.0
+        flags = self.norm_flags if env_ids is None else self.norm_flags[env_ids]
+        return torch.where(flags != 0, self._object_sum(alphas), loss) + 1.0
 
     # ---- scenes ---------------------------------------------------------------------------
     def set_scene(self, env_ids, mesh_ids, offsets) -> None:
@@ -169,24 +210,57 @@ class OcclusionEngine:
             self._full_rect = torch.tensor([0, 0, self.S - 1, self.S - 1], dtype=torch.int32, device=self.device)
         self._arect[self._arect_cur][rows] = self._full_rect
 
-    def _ring_slot(self) -> dict:
-        """The output set of this step (output_ring >= 2): persistent obs / full_state holding background outside their rects."""
-        if self._ring is None:
-            d, S, NT = self.device, self.S, self.NT
-            f32 = dict(dtype=torch.float32, device=d)
-            self._ring = []
-            for _ in range(self.output_ring):
-                obs = torch.empty(NT, 4, S, S, **f32)
-                obs[:, :3] = 1.0
-                obs[:, 3] = -1.0   # white background, depth -1 (environment.py:378)
-                fs = torch.empty(NT, S, S, 4, **f32)
-                fs[..., :3] = 3.0
-                fs[..., 3] = 0.0   # environment.py:373 with all three alphas 0
-                rect = [torch.tensor([S, S, -1, -1], dtype=torch.int32, device=d).repeat(NT, 1).contiguous() for _ in range(2)]
-                self._ring.append(dict(obs=obs, fs=fs, rect=rect, cur=0))
-        slot = self._ring[self._ring_pos]
-        self._ring_pos = (self._ring_pos + 1) % self.output_ring
+    @staticmethod
+    def _storage_refs(t: torch.Tensor) -> int:
+        """How many tensors share ``t``'s storage (views included), as the allocator counts them."""
+        return int(torch._C._storage_Use_Count(t.untyped_storage()._cdata))
+
+    def _new_output_set(self) -> dict:
+        """One persistent output set: obs / full_state filled with background, two rect arrays saying where it is not."""
+        d, S, NT = self.device, self.S, self.NT
+        f32 = dict(dtype=torch.float32, device=d)
+        obs = torch.empty(NT, 4, S, S, **f32)
+        obs[:, :3] = 1.0
+        obs[:, 3] = -1.0   # white background, depth -1 (environment.py:378)
+        fs = torch.empty(NT, S, S, 4, **f32)
+        fs[..., :3] = 3.0
+        fs[..., 3] = 0.0   # environment.py:373 with all three alphas 0
+        rect = [torch.tensor([S, S, -1, -1], dtype=torch.int32, device=d).repeat(NT, 1).contiguous() for _ in range(2)]
+        slot = dict(obs=obs, fs=fs, rect=rect, cur=0, event=None)
+        slot["refs0"] = (self._storage_refs(obs), self._storage_refs(fs))  # with nobody but this dict holding them
         return slot
+
+    def _set_is_free(self, slot) -> bool:
+        return (self._storage_refs(slot["obs"]), self._storage_refs(slot["fs"])) == slot["refs0"]
+
+    def pick_output_set(self):
+        """Choose the output set of the NEXT whole-batch step: (index, set) - or (None, None) for freshly allocated tensors
+        (no ring, no recycling, or every set of a full recycling pool still has a live view somewhere).  The choice
+        sticks until that step has launched."""
+        if self._picked is not None:
+            return self._picked
+        if self.output_ring:
+            if self._ring is None or len(self._ring) != self.output_ring:
+                self._ring = [self._new_output_set() for _ in range(self.output_ring)]
+                self._ring_pos = 0
+            k = self._ring_pos
+            self._ring_pos = (self._ring_pos + 1) % self.output_ring
+            self._picked = (k, self._ring[k])
+        elif self.output_recycle and self.R:
+            if self._ring is None:
+                self._ring = []
+            self._picked = (None, None)
+            for k, slot in enumerate(self._ring):
+                if self._set_is_free(slot):
+                    self._picked = (k, slot)
+                    break
+            else:
+                if len(self._ring) < self.output_recycle:
+                    self._ring.append(self._new_output_set())
+                    self._picked = (len(self._ring) - 1, self._ring[-1])
+        else:
+            self._picked = (None, None)
+        return self._picked
 
     # ---- workspace ------------------------------------------------------------------------
     def _scene_struct(self, n, scene_mesh, scene_offset, skip=None, pix_weight=None) -> nat.OccScene:
@@ -414,7 +488,7 @@ class OcclusionEngine:
         out = self._render(idx, nat.CAM_LOOKAT, None, nat.RENDER_SOFT | nat.RENDER_HARD)
         loss = out["loss"]
         self.full_reward[sel] = loss
-        self.object_mass[sel] = loss + 1.0  # normWithObjectSize=False (environment.py:208,324)
+        self.object_mass[sel] = self._reset_mass(loss, self.alphas[sel] if self._norm_host.any() else None, idx)  # environment.py:324
         return out["obs"], loss, out["full_state"]
 
     def evaluate_scenes(self, mesh_ids, offsets, radius, azimuth, elevation):
@@ -470,7 +544,7 @@ class OcclusionEngine:
         self.age[e] = 0
         loss = res["loss"][c]
         self.full_reward[e] = loss
-        self.object_mass[e] = loss + 1.0
+        self.object_mass[e] = self._reset_mass(loss, res["alphas"][c] if self._norm_host.any() else None, e)
 
     def render_hard(self, env_ids=None):
         """render() (environment.py:332-347): hard RGB-D at the current camera_position."""
@@ -496,6 +570,8 @@ class OcclusionEngine:
         self._res_obs[sl] = res["obs"][c]
         self._res_fs[sl] = res["full_state"][c]
         self._res_loss[sl] = res["loss"][c]
+        if self._norm_host.any():
+            self._res_objsum[sl] = self._object_sum(res["alphas"][c])
         self._alphas_all[self.N + sl] = res["alphas"][c]
         self._alpha_touch(self.N + sl)
         self._cam_all[self.N + sl] = res["cam"][c]
@@ -541,6 +617,10 @@ class OcclusionEngine:
         opts.arect = self._arect[self._arect_cur].data_ptr()
         if out.get("rect") is not None:
             opts.rect = out["rect"].data_ptr()
+        if self._norm_host.any():
+            # the slots rendered by this step (PENDING until the pairing below runs): their sum_px (a1+a2+a3)^2
+            self._object_sum(self._alphas_all[N:], gate=self.rs_state, gate_value=nat.RS_PENDING, out=self._res_objsum)
+            opts.norm_flags, opts.slot_objsum = self.norm_flags.data_ptr(), self._res_objsum.data_ptr()
         st = nat.OccEnvState()
         st.el, st.az, st.radius = self._el_all.data_ptr(), self._az_all.data_ptr(), self._rad_all.data_ptr()
         st.campos, st.cam, st.alphas = self.camera_position.data_ptr(), self._cam_all.data_ptr(), self._alphas_all.data_ptr()
@@ -614,8 +694,9 @@ class OcclusionEngine:
         st = self._stream()
         ro = nat.OccRenderOut()
         out = {}
-        if self.output_ring:
-            slot = self._ring_slot()
+        _, slot = self.pick_output_set()
+        self._picked = None
+        if slot is not None:
             obs, fs = slot["obs"], slot["fs"]
             rp, rn = slot["rect"][slot["cur"]], slot["rect"][slot["cur"] ^ 1]
             slot["cur"] ^= 1

@@ -142,7 +142,9 @@ def sample_scene(dataset, pool: MeshPool, num_objects: int = 3) -> Tuple[List[in
 class OcclusionEnv:
     def __init__(self, data=None, img_size=512):
         self.metadata = "Blablabla"
-        self.normWithObjectSize = False
+        self._engine: Optional[OcclusionEngine] = None
+        self._slot = 0
+        self._norm_with_object_size = False
         self.img_size = img_size
         self.device = torch.device("cuda:0") if torch.cuda.is_available() else torch.device("cpu")
         self.shapenet_dataset = data
@@ -151,8 +153,6 @@ class OcclusionEnv:
         self.action_space = Box(low=-0.1, high=0.1, shape=(2,))
         self.renderMode = ""  # 'human'
         self.image = None
-        self._engine: Optional[OcclusionEngine] = None
-        self._slot = 0
         self._scene: Optional[Tuple[List[int], List[List[float]]]] = None
         self.faces_per_bin = 10000
 
@@ -162,18 +162,32 @@ class OcclusionEnv:
         if engine.S != self.img_size:
             raise ValueError("all envs of a VecEnv must share img_size")
         self._engine, self._slot = engine, slot
+        engine.set_norm_with_object_size(slot, self._norm_with_object_size)
 
     def _eng(self) -> OcclusionEngine:
         if self._engine is None:
             dev = torch.device(f"cuda:{torch.cuda.current_device()}") if torch.cuda.is_available() else self.device
             self._engine = OcclusionEngine(shared_pool(dev), 1, self.img_size, device=dev)
             self._slot = 0
+            self._engine.set_norm_with_object_size(0, self._norm_with_object_size)
         return self._engine
 
     def _ids(self):
         return None if self._eng().N == 1 else [self._slot]
 
     # ---- state exposed like the reference's attributes --------------------------------------
+    @property
+    def normWithObjectSize(self) -> bool:
+        """environment.py:208,324: True = reset() sets objectMass = sum_px (a1 + a2 + a3)^2 + 1 (the silhouettes' own mass)
+        instead of loss + 1; takes effect at the env's next reset, like the reference's attribute."""
+        return self._norm_with_object_size
+
+    @normWithObjectSize.setter
+    def normWithObjectSize(self, on) -> None:
+        self._norm_with_object_size = bool(on)
+        if self._engine is not None:
+            self._engine.set_norm_with_object_size(self._slot, self._norm_with_object_size)
+
     @property
     def elevation(self):
         return self._eng().elevation[self._slot:self._slot + 1]

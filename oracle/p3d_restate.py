@@ -446,6 +446,8 @@ class OracleEnv:
         # shader of the observation renderer: "flat" = HardFlatShader (environment.py:283, what the reference runs);
         # "hard_phong" / "soft_phong" = the alternatives it keeps commented out (environment.py:281-282)
         self.shader = "flat"
+        # environment.py:208: False = objectMass is the initial loss + 1; True = sum((image1 + image2 + image3).alpha ** 2) + 1
+        self.normWithObjectSize = False
 
     def _loss(self):
         sq = self.image[..., 3] ** 2
@@ -476,7 +478,9 @@ class OracleEnv:
         observation, self.image, self.alphas = self._render_all(R, T)
         loss = self._loss()
         self.fullReward = loss.detach()
-        self.objectMass = loss.detach() + 1
+        # environment.py:320,324
+        objects = self.alphas[0] + self.alphas[1] + self.alphas[2]
+        self.objectMass = (torch.sum(objects[..., 3] ** 2).detach() + 1) if self.normWithObjectSize else (loss.detach() + 1)
         return observation
 
     def step(self, action):

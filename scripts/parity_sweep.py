@@ -1,6 +1,8 @@
 """Randomised parity sweep (GPU box): many seeded scenes through the HIP engine and the CPU oracle.
     python scripts/parity_sweep.py [n_seeds [first_seed [wide]]]     -> one line per case + a summary; exit 1 on a violation.
 "wide" also varies K (100 / 50 / 8 faces per pixel), the image side (64 ... 160) and the camera distance (1.3 ... 6).
+"near" = wide cases with the camera distance restricted to 2.5 / 1.3 / 2.0 / 1.6 (the camera inside the scene: near,
+z-clipped faces - where round 4's one violation lived).
 "stage" (wide cases) checks the RASTER STAGE ALONE: the oracle's rasteriser + blend run on the engine's own face records
 (identical geometry, no projection noise between the sides) against the engine's silhouettes, at 1e-5, no classifier.
 A case is "ok" under EXACTLY the criterion of the parity tests (tests/parity_utils.py: violations): 1e-4 everywhere,
@@ -28,6 +30,13 @@ def case_of_wide(seed):
     K = (100, 50, 8)[(seed // 16) % 3]
     radius = (4.0, 2.5, 1.3, 6.0)[(seed // 48) % 4] if mesh != "mixed" else (4.0, 6.0)[(seed // 48) % 2]
     return dict(n_env=2, img=img, seed=seed, mesh=mesh, az_range=(0.6, 3.0)[seed % 2], radius=radius, faces_per_pixel=K)
+
+
+def case_of_near(seed):
+    """case_of_wide with the camera always close: radius 2.5 / 1.3 / 2.0 / 1.6 (objects reach out to z = 2)."""
+    c = case_of_wide(seed)
+    c["radius"] = (2.5, 1.3, 2.0, 1.6)[(seed // 48) % 4]
+    return c
 
 
 def stage_sweep(n, base):
@@ -68,7 +77,8 @@ if __name__ == "__main__":
     base = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     if len(sys.argv) > 3 and sys.argv[3] == "stage":
         sys.exit(stage_sweep(n, base))
-    wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
+    wide = len(sys.argv) > 3 and sys.argv[3] in ("wide", "near")
+    near = len(sys.argv) > 3 and sys.argv[3] == "near"
     import collections
 
     from tests import parity_utils as pu
@@ -77,7 +87,7 @@ if __name__ == "__main__":
     worst, bad, ties, t0 = {}, 0, 0, time.time()
     tot_pix = 0
     for seed in range(base, base + n):
-        c = case_of_wide(seed) if wide else case_of(seed)
+        c = (case_of_near(seed) if near else case_of_wide(seed)) if wide else case_of(seed)
         res = run_parity_case(**c)
         tot_pix += 2 * c["n_env"] * 3 * c["img"] * c["img"]  # reset render + step render, three objects
         v = violations(res)

@@ -155,6 +155,81 @@ def test_auto_reset_from_the_speculative_reserve(ds):
     assert torch.isfinite(r2).all()
 
 
+def test_norm_with_object_size(ds):
+    """normWithObjectSize = True (environment.py:208,320,324): reset() sets objectMass = sum_px (a1 + a2 + a3)^2 + 1 instead of
+    loss + 1, and step() divides the reward by it (:387).  (a) single env against the oracle's restatement of the same
+    lines; (b) batched: the synchronous reset, the device-side auto-reset from the reserve (the slot's stored sum) and a
+    mixed batch in which only some envs have the flag."""
+    from environment import OcclusionEnv
+    from SubProcVecEnv import SimpleVecEnv
+    from tests.parity_utils import make_case, oracle_env, run_engine
+
+    # (a) one env, engine against oracle on the same scene and action
+    case = make_case(2, 41, "synthetic")
+    from occlusionenv_amd.engine import OcclusionEngine
+
+    S = 64
+    eng = OcclusionEngine(case["pool"], 2, S)
+    eng.set_scene([0, 1], case["mesh_ids"], case["offsets"])
+    eng.set_norm_with_object_size(1, True)  # env 1 only
+    eng.reset_render(None, 4.0, case["az"], 0.0)
+    al = eng.alphas[1].clone()  # the reset render's silhouettes
+    assert float(eng.object_mass[1]) == pytest.approx(float((al.sum(0) ** 2).sum()) + 1.0, rel=1e-5)
+    assert float(eng.object_mass[0]) == pytest.approx(float(eng.full_reward[0]) + 1.0)
+    a = case["actions"].cuda().requires_grad_(True)
+    _, reward, _, _, _ = eng.step(a)
+    reward.sum().backward()
+    for i, norm in ((0, False), (1, True)):
+        env = oracle_env(case, i, S)
+        env.normWithObjectSize = norm
+        env.reset(azimuth=float(case["az"][i]))
+        ao = case["actions"][i].clone().requires_grad_(True)
+        _, r, _, _ = env.step(ao)
+        r.backward()
+        assert float(eng.object_mass[i]) == pytest.approx(float(env.objectMass), rel=1e-5), (i, norm)
+        assert float(reward[i]) == pytest.approx(float(r), abs=1e-4)
+        assert float((a.grad[i].cpu() - ao.grad).norm()) <= 1e-4 * max(float(ao.grad.norm()), 1e-3) + 1e-7
+
+    # (b) the batched env: flags follow the env objects' attribute through every reset path
+    np.random.seed(4)
+    N = 16
+    venv = SimpleVecEnv([lambda: OcclusionEnv(ds, img_size=S) for _ in range(N)])
+    venv.set_attr("normWithObjectSize", True, indices=[3, 5, 6])
+    assert venv.get_attr("normWithObjectSize", indices=[3, 4]) == [True, False]
+    venv._reset_envs(list(range(N)), torch.zeros(N))
+    venv._warm_reserve()
+    e2 = venv.engine
+
+    def expect(i):
+        al = e2.alphas[i]
+        return float((al.sum(0) ** 2).sum()) + 1.0
+
+    for i in range(N):
+        want = expect(i) if i in (3, 5, 6) else float(e2.full_reward[i]) + 1.0
+        assert float(e2.object_mass[i]) == pytest.approx(want, rel=1e-5), i
+    # env 5 (flag on) and env 7 (flag off) finish: both are reset on the device from the reserve
+    for i in (5, 7):
+        off = e2.scene_offset[i].clone()
+        off[1, 0], off[2, 0] = 50.0, -50.0
+        e2.scene_offset[i] = off
+    obs, rewards, dones, infos = venv.step(torch.zeros(N, 2, device="cuda"))
+    assert bool(dones[5]) and bool(dones[7]) and "terminal_observation" in infos[5]
+    assert float(e2.object_mass[5]) == pytest.approx(expect(5), rel=1e-5)          # the slot's stored silhouette mass
+    assert float(e2.object_mass[7]) == pytest.approx(float(e2.full_reward[7]) + 1.0)  # the slot's stored loss + 1
+    assert expect(5) != pytest.approx(float(e2.full_reward[5]) + 1.0, rel=1e-3)   # and the two really differ
+    # the slots refilled after that go through the step launches (PENDING -> READY on the device) and are used too
+    for t in range(6):
+        venv.step(torch.zeros(N, 2, device="cuda"))
+    venv._drain()
+    off = e2.scene_offset[3].clone()
+    off[1, 0], off[2, 0] = 50.0, -50.0
+    e2.scene_offset[3] = off
+    _, _, dones, _ = venv.step(torch.zeros(N, 2, device="cuda"))
+    assert bool(dones[3])
+    assert float(e2.object_mass[3]) == pytest.approx(expect(3), rel=1e-5)
+    e2.check_status()
+
+
 def test_auto_reset_deferred_report_and_dry_reserve(ds):
     """The auto-reset runs on the device; the host reads its report at the NEXT step (or when infos are read).
     Five envs finish at once with four reserve slots: four are reset from the reserve by the device, the fifth by

@@ -25,12 +25,15 @@ def _seed(k):
     torch.manual_seed(k)
 
 
-def _make_venv(ds, N, S, ring=0, seed=77):
+def _make_venv(ds, N, S, ring=0, seed=77, recycle=None):
+    """``recycle``: None = the default (recycled outputs, SimpleVecEnv docstring), 0 = plain allocations every step."""
     from environment import OcclusionEnv
     from SubProcVecEnv import SimpleVecEnv
 
     _seed(seed)
     venv = SimpleVecEnv([lambda: OcclusionEnv(ds, img_size=S) for _ in range(N)])
+    if recycle is not None:
+        venv.use_recycled_outputs(recycle)
     if ring:
         venv.use_output_ring(ring)
     az0 = (torch.rand(N, generator=torch.Generator().manual_seed(seed)) * 2 - 1) * 0.6
@@ -66,30 +69,70 @@ def _rollout(venv, steps, push=None):
 
 
 def test_output_ring_never_changes_a_bit(ds):
-    """The same seeded rollout with fresh outputs and with a ring of 3 persistent output sets (the combine kernel then
-    writes only the pixel blocks that meet this step's object rects or what the set held three steps ago): every
-    observation, occlusion image, alpha plane, reward, done flag, gradient, terminal observation and reset image is
-    bit-identical - through auto-resets from the reserve (full-frame commits into a set) and through the synchronous
-    fallback (22 envs finish at once against 16 reserve slots)."""
+    """The same seeded rollout with freshly allocated outputs, with recycled outputs (the default) and with a ring of 3
+    persistent output sets (the combine kernel then writes only the pixel blocks that meet this step's object rects or
+    what the set held before): every observation, occlusion image, alpha plane, reward, done flag, gradient, terminal
+    observation and reset image is bit-identical - through auto-resets from the reserve (full-frame commits into a set)
+    and through the synchronous fallback (22 envs finish at once against 16 reserve slots)."""
     N, S, T = 64, 64, 30
     push = {4: [3], 9: [10, 11], 15: list(range(20, 42)), 22: [5]}
-    ref = _rollout(_make_venv(ds, N, S, ring=0), T, push)
-    got = _rollout(_make_venv(ds, N, S, ring=3), T, push)
-    n_done = 0
-    for t, (a, b) in enumerate(zip(ref, got)):
-        for k in ("obs", "rewards", "dones", "grad", "fs", "alphas", "pos", "images"):
-            assert torch.equal(a[k], b[k]), (t, k)
-        assert set(a["term"]) == set(b["term"])
-        for i in a["term"]:
-            assert torch.equal(a["term"][i], b["term"][i]), (t, i)
-        n_done += int(a["dones"].sum())
-    assert n_done >= 26
+    ref = _rollout(_make_venv(ds, N, S, ring=0, recycle=0), T, push)
+    for mode in (dict(ring=3), dict(recycle=None), dict(recycle=2)):
+        got = _rollout(_make_venv(ds, N, S, **mode), T, push)
+        n_done = 0
+        for t, (a, b) in enumerate(zip(ref, got)):
+            for k in ("obs", "rewards", "dones", "grad", "fs", "alphas", "pos", "images"):
+                assert torch.equal(a[k], b[k]), (mode, t, k)
+            assert set(a["term"]) == set(b["term"])
+            for i in a["term"]:
+                assert torch.equal(a["term"][i], b["term"][i]), (mode, t, i)
+            n_done += int(a["dones"].sum())
+        assert n_done >= 26
     # the ring really is a ring: the set of step t is the set of step t + 3
     venv = _make_venv(ds, 16, 64, ring=3)
     ptrs = [venv.step(torch.zeros(16, 2, device="cuda"))[0].data_ptr() for _ in range(6)]
     assert ptrs[0] == ptrs[3] and ptrs[1] == ptrs[4] and len(set(ptrs)) == 3
     with pytest.raises(ValueError):
         venv.use_output_ring(1)
+
+
+def test_recycled_outputs_never_touch_a_tensor_somebody_still_holds(ds):
+    """Recycled outputs (the default): a step's tensors come from a pool of persistent sets, and a set is reused only once
+    no view of it is alive.  (a) a rollout loop that rebinds obs / infos runs on two sets; (b) an observation and an
+    occlusion image the caller KEEPS are never overwritten - their values stay what a fresh-tensor run returned for that
+    step - while later steps move on to other sets and, at the pool's cap, to plain allocations."""
+    N, S = 32, 64
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    acts = [torch.randn(N, 2, device="cuda", generator=gen) for _ in range(13)]
+    # the reference values of every step: the same seeded env with plain allocations
+    ref_env = _make_venv(ds, N, S, recycle=0)
+    ref = []
+    for t in range(12):
+        o, _, _, inf = ref_env.step(acts[t])
+        ref.append((o.clone(), inf[0]["full_state"].clone()))
+    del ref_env, o, inf
+    venv = _make_venv(ds, N, S)
+    eng = venv.engine
+    assert eng.output_recycle >= 2 and not eng.output_ring
+    ptrs = []
+    for t in range(6):  # (a) nothing kept: obs / infos of step t die when step t + 1 returns
+        obs, _, _, infos = venv.step(acts[t])
+        assert torch.equal(obs, ref[t][0]), t
+        ptrs.append(obs.data_ptr())
+    del obs, infos
+    assert len(set(ptrs)) <= 3 and len(eng._ring) <= 3, (ptrs, len(eng._ring))
+    kept = []
+    for t in range(6, 12):  # (b) every step's obs and one full_state view are KEPT
+        obs, _, _, infos = venv.step(acts[t])
+        kept.append((obs, infos[0]["full_state"]))
+    torch.cuda.synchronize()
+    assert len({o.data_ptr() for o, _ in kept}) == 6  # six live observations: six different buffers
+    assert len(eng._ring) == eng.output_recycle       # the pool stopped growing at its cap ...
+    for t, (o, f) in zip(range(6, 12), kept):          # ... and nothing that is held was overwritten
+        assert torch.equal(o, ref[t][0]) and torch.equal(f, ref[t][1]), t
+    del kept, obs, infos, o, f
+    venv.step(acts[12])
+    assert len(eng._ring) == eng.output_recycle  # released sets are found again: no growth, no leak
 
 
 def test_ring_sets_hold_background_outside_their_rects(ds):
