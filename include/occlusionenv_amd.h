@@ -61,7 +61,8 @@ extern "C" {
 #define OCC_LOG_CAP 12288  /* candidate-log entries per persistent wave (20 B each); a log about to fill up is compacted
                               in place to every overflowing pixel's K nearest.  Must be >= 64*OCC_MAX_K + 2048 + 64 */
 #endif
-#define OCC_LOG_ENTRY_BYTES 20 /* (depth key u32, pixel | face sequence << 6 u32) + payload (1-p, p dd/del, p dd/daz) f32 x3 */
+#define OCC_LOG_ENTRY_BYTES 28 /* (depth key u32, pixel | face sequence << 6 u32) + payload (1-p, p dd/del, p dd/daz) f32 x3
+                                  + 8 B of the selection's compacted copy of the entries of the pixels that hold more than K */
 #define OCC_MAX_K 128      /* largest faces_per_pixel the fused path accepts */
 
 /* occ_camera modes */
@@ -124,7 +125,8 @@ typedef struct OccWorkspace {
     int32_t* objrect;   /* (n_env,3,4) block rect bx0,by0,bx1,by1 (inclusive, OCC_BLOCK-pixel units) */
     uint32_t* queue;    /* (8,16) one work-queue head per XCD group, a 64-B line each (zeroed by occ_render) */
     float* lists;       /* (n_slots, OCC_LOG_CAP*OCC_LOG_ENTRY_BYTES) per-wave K-buffer = wave-compacted candidate log:
-                           OCC_LOG_CAP payloads of 12 B, then OCC_LOG_CAP (key, tag) pairs of 8 B (structure of arrays) */
+                           OCC_LOG_CAP payloads of 12 B, then OCC_LOG_CAP (key, tag) pairs of 8 B (structure of arrays), then
+                           OCC_LOG_CAP x 8 B for the exact top-K's compacted copy of the entries it has to rank */
     float* partials;    /* (n_env,ceil(S*S/256),4) per-block loss / gradient partial sums */
     int32_t* status;    /* (n_env) OCC_STATUS_* bits, OR-ed in; caller clears */
     int32_t* offsets;   /* (8*3*ceil(n_env/8)+1) rect order only (order == NULL): first work item of every (env, object), XCD-major */

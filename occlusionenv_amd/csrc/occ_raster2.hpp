@@ -56,7 +56,7 @@
 // OCC_LOG_CAP (include/occlusionenv_amd.h): log entries per wave; must hold a compacted log (64 * OCC_MAX_K) plus the
 // pairs of one batch
 static_assert(OCC_LOG_CAP >= 64 * OCC_MAX_K + 2048 + 64, "OCC_LOG_CAP too small");
-static_assert(OCC_LOG_ENTRY_BYTES == 20, "12 B payload + 8 B (key, tag)");
+static_assert(OCC_LOG_ENTRY_BYTES == 28, "12 B payload + 8 B (key, tag) + 8 B (key, tag, index) of the selection's own compacted copy");
 #define OCC_LOG_BYTES ((size_t)OCC_LOG_CAP * OCC_LOG_ENTRY_BYTES)
 
 constexpr int kT2 = 8;         // tile side in pixels (== OCC_TILE)
@@ -73,6 +73,15 @@ constexpr int kSelStride = kSelDw + 1;  // dwords per pixel in LDS: odd, so that
 #endif
 constexpr int kSweepU = OCC_SWEEP_U;     // 64-entry rows of the log per sweep group; two groups are in flight (wider groups /
                                // 16-byte double rows were measured slower: they push the kernel into spilling)
+#ifndef OCC_SWEEP_RING
+#define OCC_SWEEP_RING 2
+#endif
+// Round 5: the final sweep issues the payload loads of a group's kept entries right after the group's decisions and applies
+// them one group later (1.947 -> 1.899 ms).  The sweeps keep kRingGroups groups of kSweepU rows of (key, tag) in flight;
+// more than two buys nothing (three: 1.902 ms, four: 1.939 ms - the registers cost more than the latency hidden), and rows
+// are still handled kSweepU at a time: the window look-ups of a group are independent LDS reads - one row at a time,
+// twelve rows deep in flight, was measured 9 % SLOWER (2.13 - 2.19 ms): the LDS round trips then lie end to end.
+constexpr int kRingGroups = OCC_SWEEP_RING;  // groups of kSweepU rows of (key, tag) in flight per sweep
 constexpr int kListCap = 8;    // boundary-bucket entries per pixel that the owner lane resolves itself
 #ifndef OCC_ACC_COPY_BITS
 #define OCC_ACC_COPY_BITS 2
@@ -88,7 +97,13 @@ struct LogPay {  // 12 bytes, moved with one dwordx3 access
 struct WaveLog {
     LogPay* __restrict__ pay;
     uint2* __restrict__ kt;    // (order-preserving depth key, pixel of the tile 0..63 | face sequence number << 6)
+    // Round 5: what the selection's LATER sweeps read.  Its first sweep (the first histogram pass) copies the entries of
+    // the pixels that hold more than K candidates - 63 % of the log of a tile that needs selection on the bench - into
+    // this region, in log order: (key, pixel | low ten bits of the face sequence number << 6 | log index << 16).  The
+    // other histogram passes and the final sweep then visit those rows only.
+    uint2* __restrict__ kt2;
 };
+static_assert(OCC_LOG_CAP <= 65536, "the compacted copy keeps the log index in sixteen bits");
 
 // Accumulator slot of pixel pix (= 8 py + px) in copy cpy.  A 16-byte LDS access is served 16 lanes at a time, one per
 // residue of the slot index mod 16: the column is rotated by 3 every second row and the copy stride is 1 mod 16, so that
@@ -184,6 +199,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
         char* base = reinterpret_cast<char*>(P.ws.lists) + (size_t)blockIdx.x * OCC_LOG_BYTES;
         lg.pay = reinterpret_cast<LogPay*>(base);
         lg.kt = reinterpret_cast<uint2*>(base + (size_t)OCC_LOG_CAP * 12);
+        lg.kt2 = reinterpret_cast<uint2*>(base + (size_t)OCC_LOG_CAP * 20);
     }
     ciptr offs = as_const(P.ws.offsets);
     ciptr ord = as_const(reinterpret_cast<const int*>(P.ws.order));  // null: rect order through offs
@@ -313,7 +329,10 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
         // Leaves the sums of the lane's own pixel's K nearest in acc2 (and the largest kept key in s_kmax2 when compacting) and returns whether
         // this lane's pixel was one of them.  COMPACT also rewrites the log so that it holds exactly the entries still
         // accounted for, and folds the selected sums back into the accumulator copies.
-        auto select_topk = [&](const bool compact) __attribute__((always_inline)) -> bool {
+        auto select_topk = [&](auto compact_c) __attribute__((always_inline)) -> bool {
+            constexpr bool compact = decltype(compact_c)::value;
+            // rows of (key, tag) in flight: the in-loop compaction runs with the next batch's records in registers
+            constexpr int kRingG = compact ? 2 : kRingGroups;
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every log entry written so far is in memory before it is swept
             wave_lds_sync();
             (void)OCC_BOUND(nlog >= 0 && nlog <= OCC_LOG_CAP, 44, nlog, compact);
@@ -330,13 +349,16 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 sh = range ? max(0, (32 - __builtin_clz(range)) - kSelBits) : 0;
             }
             // A sweep visits the log in groups of kSweepU rows of 64 entries; the next group's loads are issued before
-            // the current one is processed (two groups = 8 KB in flight per wave: a sweep is pure memory latency)
+            // the current one is processed (two groups = 8 KB in flight per wave: a sweep is pure memory latency).
+            // src / nsrc: what is swept - the log, or (final selection, after its first pass) the compacted copy
+            const uint2* __restrict__ src = lg.kt;
+            int nsrc = nlog;
             auto load_group = [&](const int e0, auto& kt) __attribute__((always_inline)) {
                 constexpr int U = (int)(sizeof(kt) / sizeof(kt[0]));
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int e = e0 + u * 64 + lane;
-                    kt[u] = e < nlog ? lg.kt[e] : make_uint2(0u, kNoEntry);
+                    kt[u] = e < nsrc ? src[e] : make_uint2(0u, kNoEntry);
                 }
             };
             constexpr int kGroup = 64 * kSweepU;
@@ -346,7 +368,11 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             bool done = !ovf;
             s_sel[lane] = make_uint2(L, done ? 255u : (uint32_t)sh);
             OCC_T(10);  // selection: set-up
+            OCC_STAT(9, nlog);                       // log entries a selection sweeps (per pass)
+            OCC_STAT(10, __popcll(__ballot(ovf)));   // pixels that go through selection
+            int pass = 0;
             while (__ballot(!done)) {
+                OCC_STAT(8, 1);                      // histogram passes
 #pragma unroll
                 for (int i = 0; i < kSelStride; ++i) hist[lane + 64 * i] = 0u;  // the whole array, lane-contiguous
                 wave_lds_sync();
@@ -363,16 +389,48 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                         }
                     }
                 };
+                // FINAL selection, first pass: the entries of the pixels under selection are also copied, in log order, to the
+                // compacted region that every later sweep reads (WaveLog.kt2)
+                int n2 = 0;
+                auto bump_copy = [&](const int e0, const uint2 (&kt)[kSweepU]) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int u = 0; u < kSweepU; ++u) {
+                        bool ov = false;
+                        if (kt[u].y != kNoEntry) {
+                            const uint32_t px = kt[u].y & 63u;
+                            const uint2 w = s_sel[px];
+                            if (w.y < 32u) {
+                                ov = true;
+                                const uint32_t d = (kt[u].x - w.x) >> w.y;
+                                if (kt[u].x >= w.x && d < (1u << kSelBits)) atomicAdd(&hist[px * kSelStride + (d >> 1)], 1u << (16 * (d & 1u)));
+                            }
+                        }
+                        const unsigned long long m = __ballot(ov);
+                        if (ov) lg.kt2[n2 + lane_rank(m)] = make_uint2(kt[u].x, (kt[u].y & 0xFFFFu) | (uint32_t)(e0 + u * 64 + lane) << 16);
+                        n2 += __popcll(m);
+                    }
+                };
                 {
-                    uint2 ka[kSweepU], kb[kSweepU];
-                    load_group(0, ka);
-                    for (int e0 = 0; e0 < nlog; e0 += 2 * kGroup) {
-                        load_group(e0 + kGroup, kb);
-                        bump(ka);
-                        load_group(e0 + 2 * kGroup, ka);
-                        bump(kb);
+                    // kRingG groups of kSweepU rows in flight: the group that was just consumed is requested again at once
+                    uint2 ring[kRingG][kSweepU];
+#pragma unroll
+                    for (int gi = 0; gi < kRingG; ++gi) load_group(gi * kGroup, ring[gi]);
+                    for (int e0 = 0; e0 < nsrc; e0 += kRingG * kGroup) {
+#pragma unroll
+                        for (int gi = 0; gi < kRingG; ++gi) {
+                            if (!compact && pass == 0) bump_copy(e0 + gi * kGroup, ring[gi]);
+                            else bump(ring[gi]);
+                            load_group(e0 + (kRingG + gi) * kGroup, ring[gi]);
+                        }
                     }
                 }
+                if (!compact && pass == 0) {
+                    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the copy is in memory before it is swept
+                    src = lg.kt2;
+                    nsrc = n2;
+                    OCC_STAT(13, n2);  // entries in the compacted copy
+                }
+                pass += 1;
                 wave_lds_sync();
                 OCC_T(11);  // selection: histogram sweeps
                 if (!done) {
@@ -401,6 +459,10 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     } else {
                         sh = max(0, sh - kSelBits);
                     }
+#ifdef OCC_EXP_HIST_ONCE  // timing experiment only (results void): what the histogram passes after the first cost
+                    done = true;
+                    mode = kAll;
+#endif
                     s_sel[lane] = make_uint2(L, done ? 255u : (uint32_t)sh);
                 }
                 wave_lds_sync();
@@ -453,7 +515,11 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #pragma unroll
                 for (int u = 0; u < kU; ++u) {
                     const int e = e0 + u * 64 + lane;
+#ifdef OCC_EXP_FS_NO_PAY  // timing experiment only (results void): what the final sweep's dependent payload loads cost
+                    pv[u] = LogPay{__uint_as_float(0x3f800000u | ((readdm >> u) & 1u)), 0.f, (float)e};
+#else
                     pv[u] = (((readdm | (compact ? keepm : 0u)) >> u) & 1u) ? lg.pay[e] : LogPay{1.f, 0.f, 0.f};
+#endif
                 }
 #pragma unroll
                 for (int u = 0; u < kU; ++u) {
@@ -469,7 +535,13 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                         const uint32_t grp = tag >> (6 + kCopyBits);
                         const int slot = acc_slot((int)((tag >> 6) & (uint32_t)(kCopies - 1)), (int)(tag & 63u));
                         unsigned long long rem = __ballot(act);
+                        OCC_STAT(11, __popcll(rem));  // entries re-accumulated
+#ifdef OCC_EXP_FS_NO_RMW  // timing experiment only (results void): what the final sweep's RMW sub-passes cost
+                        asm volatile("" ::"v"(pv[u].q), "v"(pv[u].ge), "v"(pv[u].ga), "v"(slot), "v"(grp));
+                        rem = 0ull;
+#endif
                         while (rem) {
+                            OCC_STAT(12, 1);          // RMW sub-passes of the final sweep
                             const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)grp, __ffsll(rem) - 1);
                             const bool mine = act && grp == g0;
                             if (mine) {
@@ -498,21 +570,105 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     }
                 }
             };
-            if (compact) {  // in-place rewrite: a group's loads must not run ahead of the previous group's stores
+            if constexpr (compact) {  // in-place rewrite: a group's loads must not run ahead of the previous group's stores
                 uint2 ka[kSweepU];
                 for (int e0 = 0; e0 < nlog; e0 += kGroup) {
                     load_group(e0, ka);
                     settle(e0, ka);
                 }
             } else {
-                uint2 ka[kSweepU], kb[kSweepU];
-                load_group(0, ka);
-                for (int e0 = 0; e0 < nlog; e0 += 2 * kGroup) {
-                    load_group(e0 + kGroup, kb);
-                    settle(e0, ka);
-                    load_group(e0 + 2 * kGroup, ka);
-                    settle(e0 + kGroup, kb);
+                // Group pipeline: decide(group g) - the window tests, the tie counters and boundary lists, in log order -
+                // issues the payload loads of its kept entries at once; apply(group g - 1) re-accumulates a group whose
+                // payloads have had a group's work to arrive.  Groups are applied in log order, sub-passes as in the evaluation
+                // rounds: the sums come out bit for bit as before.
+                uint2 ring[kRingG][kSweepU];
+                uint32_t ptag[kSweepU];  // tag | 1 << 31 of an entry that is re-accumulated, else 0
+                LogPay ppay[kSweepU];
+#pragma unroll
+                for (int gi = 0; gi < kRingG; ++gi) load_group(gi * kGroup, ring[gi]);
+#pragma unroll
+                for (int u = 0; u < kSweepU; ++u) {
+                    ptag[u] = 0u;
+                    ppay[u] = LogPay{1.f, 0.f, 0.f};
                 }
+                auto apply = [&]() __attribute__((always_inline)) {
+#pragma unroll
+                    for (int u = 0; u < kSweepU; ++u) {
+                        const bool act = (ptag[u] >> 31) != 0u;
+                        const uint32_t tag = ptag[u] & 0xFFFFu;
+                        // (ten bits of the face sequence number: a 64-entry row spans fewer than 64 faces, the groups of four
+                        // consecutive faces inside it are told apart by their low bits)
+                        const uint32_t grp = tag >> (6 + kCopyBits);
+                        const int slot = acc_slot((int)((tag >> 6) & (uint32_t)(kCopies - 1)), (int)(tag & 63u));
+                        unsigned long long rem = __ballot(act);
+                        OCC_STAT(11, __popcll(rem));  // entries re-accumulated
+#ifdef OCC_EXP_FS_NO_RMW  // timing experiment only (results void): what the final sweep's RMW sub-passes cost
+                        asm volatile("" ::"v"(ppay[u].q), "v"(ppay[u].ge), "v"(ppay[u].ga), "v"(slot), "v"(grp));
+                        rem = 0ull;
+#endif
+                        while (rem) {
+                            OCC_STAT(12, 1);  // RMW sub-passes of the final sweep
+                            const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)grp, __ffsll(rem) - 1);
+                            const bool mine = act && grp == g0;
+                            if (mine) {
+                                float4 a = s_acc[slot];
+                                a.x *= ppay[u].q;
+                                if (GRAD) {
+                                    a.y += ppay[u].ge;
+                                    a.z += ppay[u].ga;
+                                }
+                                a.w += 1.0f;
+                                s_acc[slot] = a;
+                            }
+                            rem &= ~__ballot(mine);
+                        }
+                    }
+                };
+                auto decide = [&](const uint2 (&kt)[kSweepU]) __attribute__((always_inline)) {
+                    uint32_t readdm = 0u;
+#pragma unroll
+                    for (int u = 0; u < kSweepU; ++u) {  // decisions in log order (ties are served first come)
+                        if (kt[u].y != kNoEntry) {
+                            const uint32_t px = kt[u].y & 63u;
+                            const uint2 w = s_sel[px];
+                            const uint32_t shp = w.y & 255u;
+                            if (shp < 32u) {  // (a pixel that does not overflow keeps its accumulated sums)
+                                bool r = false;
+                                if (kt[u].x < w.x) {
+                                    r = true;
+                                } else if (((kt[u].x - w.x) >> shp) == 0u) {
+                                    if ((w.y >> 8) == (uint32_t)kList) {
+                                        const uint32_t sl = atomicAdd(&s_lcnt[px], 1u);
+                                        if (sl < (uint32_t)kListCap) blist[px * kListCap + sl] = make_uint2(kt[u].x, kt[u].y >> 16);  // (key, log index)
+                                    } else {
+                                        r = (int)atomicSub(&s_take[px], 1u) > 0;  // the first `take` arrivals are kept
+                                    }
+                                }
+                                if (r) readdm |= 1u << u;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kSweepU; ++u) {
+                        const bool r = (readdm >> u) & 1u;
+                        const uint32_t e = kt[u].y >> 16;  // index of the entry in the log itself: where its payload is
+                        ptag[u] = r ? ((kt[u].y & 0xFFFFu) | 0x80000000u) : 0u;
+#ifdef OCC_EXP_FS_NO_PAY  // timing experiment only (results void): what the final sweep's dependent payload loads cost
+                        ppay[u] = LogPay{__uint_as_float(0x3f800000u | (r ? 1u : 0u)), 0.f, (float)e};
+#else
+                        ppay[u] = r ? lg.pay[e] : LogPay{1.f, 0.f, 0.f};
+#endif
+                    }
+                };
+                for (int e0 = 0; e0 < nsrc; e0 += kRingG * kGroup) {
+#pragma unroll
+                    for (int gi = 0; gi < kRingG; ++gi) {
+                        apply();  // the group before this one
+                        decide(ring[gi]);
+                        load_group(e0 + (kRingG + gi) * kGroup, ring[gi]);
+                    }
+                }
+                apply();  // the last group
             }
             wave_lds_sync();
             if (ovf) acc2 = own_fold();
@@ -748,7 +904,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 if (SOFT && nlog + ptot > OCC_LOG_CAP) {
                     // rare: the log could fill up inside this batch -> keep every overflowing pixel's K nearest,
                     // compact the log, go on with tighter bounds
-                    select_topk(true);
+                    select_topk(std::true_type{});
                     if (dense && own_count() >= K) {
                         lim_on = true;
                         bnd = min(bnd, own_kmax());
@@ -967,7 +1123,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 if (nolog) {  // cannot happen (the class bound counts every face that can reach the tile): say so loudly
                     if (lane == 0) atomicOr(&P.ws.status[eo / 3], OCC_STATUS_LIST_OVERFLOW);
                 } else {
-                    selected = select_topk(false);  // more than K candidates: keep the K nearest in z, A.4
+                    selected = select_topk(std::false_type{});  // more than K candidates: keep the K nearest in z, A.4
                 }
             }
 #endif

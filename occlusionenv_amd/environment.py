@@ -134,6 +134,12 @@ def sample_scene(dataset, pool: MeshPool, num_objects: int = 3) -> Tuple[List[in
                 # environment.py:126-129: TexturesAtlas when the model has textures, else white TexturesVertex
                 pool.add(obj["verts"], obj["faces"], key=key, atlas=obj.get("textures"))
             ids.append(pool._keys[key])
+        # environment.py:126-129 gives a model TexturesAtlas when it has textures and white TexturesVertex when it has
+        # none; environment.py:191 then joins the three meshes with [P3D] join_meshes_as_scene, which RAISES when the
+        # texture types differ ("all meshes must have the same type of texture"), and reset()'s bare except draws the
+        # scene again (:329-330).  A mixed scene therefore never reaches the renderer in the reference: same here.
+        if len({pool.get_atlas(m) is not None for m in ids}) > 1:
+            raise ValueError("scene mixes textured and untextured models (the reference's join_meshes_as_scene raises)")
     x2 = float(np.random.randn())
     offsets = [[0.0, 0.0, 0.0], [x2, 0.0, distance / 2], [-x2, 0.0, float(distance)]][:num_objects]
     return ids, offsets

@@ -73,9 +73,8 @@ def main():
             torch.cuda.synchronize()
             eng.lib = lib
             w = waves or default_waves
-            if w != eng.waves_per_cu:
-                eng.waves_per_cu = w
-                eng._ws_key = None  # new persistent grid: the workspace (one log per wave) is re-made
+            eng.waves_per_cu = w
+            eng._ws_key = None  # the workspace is re-made for every variant: its sizes are the LIBRARY's (occ_workspace_query)
             for _ in range(args.warmup):
                 one_step()
             nat.check(lib.occ_profile_enable(1), "profile")

@@ -1,9 +1,10 @@
 #!/bin/bash
-# Build one variant of the HIP library for A/B runs:  bash scripts/build_variant.sh NAME [-Dflags...]  -> build/ab/libocc_NAME.so
+# Build a variant of the HIP library for A/B runs (scripts/ab_bench.py):  scripts/build_variant.sh NAME [-DFLAG ...]
+#   -> build/ab/libocc_NAME.so   (same flags as __graft_entry__.build())
 set -e
 cd "$(dirname "$0")/.."
-mkdir -p build/ab
 name=$1; shift
-hipcc --offload-arch=gfx950 -O3 -std=c++17 ${SLP:--fno-slp-vectorize} -shared -fPIC -Iinclude -Iocclusionenv_amd/csrc "$@" \
-  -o build/ab/libocc_$name.so occlusionenv_amd/csrc/occ_kernels.hip
-echo "built build/ab/libocc_$name.so"
+mkdir -p build/ab
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -shared -fPIC -Iinclude -Ioccclusionenv_amd/csrc -Ioccl -Iocclusionenv_amd/csrc \
+  -o build/ab/libocc_$name.so occlusionenv_amd/csrc/occ_kernels.hip "$@"
+echo "built build/ab/libocc_$name.so $*"

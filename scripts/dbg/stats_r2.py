@@ -15,7 +15,7 @@ for mesh, img in [("synthetic", 128), ("teapot", 128), ("mixed", 128), ("synthet
     eng.set_scene(list(range(N)), case["mesh_ids"], case["offsets"])
     eng.reset_render(None, 4.0, case["az"], 0.0)
     torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * 8)()
+    buf = (ctypes.c_ulonglong * 16)()
     lib.occ_debug_stats(buf)
     a = case["actions"].cuda().requires_grad_(True)
     eng.step(a)
@@ -25,5 +25,7 @@ for mesh, img in [("synthetic", 128), ("teapot", 128), ("mixed", 128), ("synthet
     al = eng.alphas
     npx = float((al > 0).float().sum()) / N
     print(mesh, img, "per env: items %.1f chunk_rows %.0f stagings %.0f staged_pairs %.0f iters %.0f cands %.0f "
-          "cands_in_ovf_px %.0f items_with_ovf %.1f  covered pixel-objects %.0f" % (st[0], st[5], st[1], st[2], st[3], st[4], st[6], st[7], npx), flush=True)
+          "cands_in_ovf_px %.0f items_with_ovf %.1f  covered pixel-objects %.0f | hist passes %.1f  swept log entries (per pass) %.0f  "
+          "ovf pixels %.0f  re-accumulated entries %.0f  final-sweep sub-passes %.0f" % (st[0], st[5], st[1], st[2], st[3], st[4], st[6], st[7], npx,
+                                                                                        st[8], st[9], st[10], st[11], st[12]), flush=True)
     del eng

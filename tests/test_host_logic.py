@@ -460,3 +460,36 @@ def test_pool_keys_survive_dataset_address_reuse():
         del ds
         gc.collect()
     environment.seed_scene_rng(None)
+
+
+def test_mixed_texture_scenes_are_drawn_again_like_the_reference():
+    """environment.py:126-129 wraps a textured model in TexturesAtlas and an untextured one in TexturesVertex; [P3D]
+    join_meshes_as_scene (:191) raises on a mix and reset()'s bare except draws again (:329-330): a scene whose three
+    models do not share the texture type never reaches the renderer.  sample_scene raises ValueError for such a draw -
+    every caller (OcclusionEnv._new_scene, SimpleVecEnv._refill_reserve) treats that as "draw again" - so all scenes
+    that ARE returned are uniformly textured or uniformly white."""
+    import numpy as np
+    import torch
+
+    from occlusionenv_amd import environment
+    from occlusionenv_amd.meshes import MeshPool, SyntheticShapeNet
+
+    ds = SyntheticShapeNet(n_models=8, seed=5, textured=True)
+    for i in (1, 4, 6):
+        ds.atlases[i] = None  # three of the eight models have no textures
+    pool = MeshPool("cpu")
+    environment.seed_scene_rng(11)
+    np.random.seed(11)
+    kinds, rejected = set(), 0
+    for _ in range(200):
+        try:
+            ids, _ = environment.sample_scene(ds, pool)
+        except ValueError as e:
+            assert "textured and untextured" in str(e)
+            rejected += 1
+            continue
+        tex = {pool.get_atlas(m) is not None for m in ids}
+        assert len(tex) == 1
+        kinds |= tex
+    assert kinds == {True, False} and rejected > 50  # both uniform kinds occur; most draws of this pool are mixed
+    environment.seed_scene_rng(None)
