@@ -333,6 +333,8 @@ typedef struct OccPpoState {
     float *adam_m, *adam_v;       /* OCC_PPO_PARAMS each */
     float* adam_step;             /* (1) step count as float (torch's capturable Adam keeps it on the device too) */
 } OccPpoState;
+/* The block cap this library was built with (OCC_PPO_MAX_BLOCKS): scratch must hold occ_ppo_max_blocks() * (OCC_PPO_PARAMS + 2) floats. */
+int occ_ppo_max_blocks(void);
 int occ_ppo_update(const float* feats, const float* actions, const float* old_logprob, const float* returns, int64_t M,
                    float action_var, float eps_clip, float lr_actor, float lr_critic, float beta1, float beta2,
                    float adam_eps, const OccPpoState* state, int n_epochs, float* losses, float* scratch,
@@ -374,15 +376,15 @@ int occ_reset_commit(const int32_t* pairs, int n, float* el, float* az, float* r
  * -- rendered by a step; loss > 0.1 or 10th try --> OCC_RS_READY (else back to EMPTY, try count kept) -- taken by
  * a finished env --> EMPTY (tries = 0).  Only the host leaves EMPTY, only the device leaves PENDING / READY.
  *
- * One call = three launches: (0) the rows this step rendered for PENDING slots (observation, full_state, loss) are
- * copied into the persistent OccReserveStore - READY slots are not rendered again (OccScene.skip), their last render
- * stays valid; (1) a single block ages the PENDING slots, lists finished envs and READY slots in index order, pairs
- * them and refreshes the skip mask (rendered next step = PENDING only); (2) every pair copies the slot's stored
- * state into the env's rows (as occ_reset_commit), saving the env's final observation to term_obs[slot] first
- * (info["terminal_observation"]).
+ * One call = two launches (three until ABI v8): (1) a single block ages the PENDING slots, lists finished envs and READY
+ * slots in index order, pairs them and refreshes the skip mask (rendered next step = PENDING only); (2) per slot: the rows
+ * this step rendered for a slot that was PENDING and is not taken now (observation, full_state, loss) are copied into the
+ * persistent OccReserveStore - READY slots are not rendered again (OccScene.skip), their last render stays valid - and
+ * every pair copies the slot's last render (this step's rows, or the store) and state into the env's rows (as
+ * occ_reset_commit), saving the env's final observation to term_obs[slot] first (info["terminal_observation"]).
  * report (n_env + 2*n_reserve + 2 int32): [0,n_env) 1 = done, 2 = time limit (OccAutoResetOpts) | [n_env, +n_reserve) slot state AFTER the call |
  * [.., +n_reserve) env that took the slot this call or -1 | any status bit | finished envs left without a slot.
- * pairs: scratch, 2 + 2*n_reserve int32.  Arrays of OccEnvState hold n_env + n_reserve rows except
+ * pairs: scratch, 2 + 3*n_reserve int32.  Arrays of OccEnvState hold n_env + n_reserve rows except
  * campos / full_reward / object_mass (n_env rows); obs_all has n_env + n_reserve rows.
  */
 #define OCC_RS_EMPTY 0
@@ -430,6 +432,10 @@ typedef struct OccAutoResetOpts {
      * sum for the stored render of every reserve slot (occ_object_mass).  Both NULL: loss + 1 for every env. */
     const int32_t* norm_flags;
     const float* slot_objsum;
+    /* A second copy of `report`, written by the pairing launch itself into PINNED HOST memory that the device can address
+     * (hipHostMalloc / torch pin_memory): the host reads it after an event recorded behind this call - no copy launch.  Its
+     * first n_env words must be ZERO on entry: only the entries of envs that are reset (1 / 2) are written. */
+    int32_t* report_host;
 } OccAutoResetOpts;
 
 int occ_auto_reset(const uint8_t* done, const float* loss_all, const int32_t* status, int n_env, int n_reserve,
@@ -446,8 +452,9 @@ int occ_auto_reset(const uint8_t* done, const float* loss_all, const int32_t* st
 int occ_object_mass(const float* alphas, int n_rows, int img, const int32_t* gate, int gate_value, float* out, void* stream);
 
 /*
- * Host -> reserve: n packed rows of 13 words (slot, mesh id x3, offset x9 as float bits) already in device
- * memory; scatters them into scene_mesh / scene_offset rows n_env + slot and marks the slots OCC_RS_PENDING.
+ * Host -> reserve: n packed rows of 13 words (slot, mesh id x3, offset x9 as float bits) in device memory or in
+ * pinned host memory the device can address (then no copy launch is needed: the rows are read when the kernel runs, so
+ * the host must leave them alone until it has synchronised with something later on the stream); scatters them into scene_mesh / scene_offset rows n_env + slot and marks the slots OCC_RS_PENDING.
  */
 int occ_reserve_refill(const int32_t* packed, int n, int n_env, int n_reserve, int32_t* scene_mesh, float* scene_offset,
                        int32_t* rs_state, int32_t* skip, void* stream);

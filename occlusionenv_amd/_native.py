@@ -18,7 +18,7 @@ CAM_STRIDE = 48
 REC_STRIDE = 32
 TILE = 8
 LOG_CAP = 12288
-LOG_ENTRY_BYTES = 20
+LOG_ENTRY_BYTES = 28
 MAX_K = 128
 CAM_STEP, CAM_LOOKAT, CAM_POSITION = 0, 1, 2
 RENDER_SOFT, RENDER_HARD, RENDER_GRAD = 1, 2, 4
@@ -127,7 +127,8 @@ class OccCameraArgs(C.Structure):
 
 class OccAutoResetOpts(C.Structure):
     _fields_ = [("age", C.c_void_p), ("max_ep_len", C.c_int32), ("rect", C.c_void_p), ("arect", C.c_void_p),
-                ("reset_full_state", C.c_void_p), ("norm_flags", C.c_void_p), ("slot_objsum", C.c_void_p)]
+                ("reset_full_state", C.c_void_p), ("norm_flags", C.c_void_p), ("slot_objsum", C.c_void_p),
+                ("report_host", C.c_void_p)]
 
 
 class OccEnvState(C.Structure):
@@ -142,7 +143,7 @@ class OccPpoState(C.Structure):
 
 PPO_FEATURES = 256
 PPO_PARAMS = 3 * PPO_FEATURES + 3
-PPO_SCRATCH_FLOATS = 128 * (PPO_PARAMS + 2)
+PPO_SCRATCH_FLOATS = 128 * (PPO_PARAMS + 2)  # for the default OCC_PPO_MAX_BLOCKS; ppo_scratch_floats() asks the library
 
 
 class OccReserveStore(C.Structure):
@@ -177,6 +178,7 @@ SYMBOLS = {
                                               C.c_void_p]),
     "occ_ppo_update": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 7 + [C.POINTER(OccPpoState), C.c_int, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "occ_ppo_max_blocks": (C.c_int, []),
     "occ_pool8": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "occ_step_flags": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "occ_reset_commit": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 13 + [C.c_int, C.c_void_p]),
@@ -218,6 +220,11 @@ def load() -> C.CDLL:
         raise NativeError(f"ABI mismatch: library {lib.occ_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+def ppo_scratch_floats() -> int:
+    """Scratch floats occ_ppo_update needs, from the block cap the LIBRARY was built with (-DOCC_PPO_MAX_BLOCKS)."""
+    return int(load().occ_ppo_max_blocks()) * (PPO_PARAMS + 2)
 
 
 def check(rc: int, what: str) -> None:

@@ -218,10 +218,9 @@ __global__ __launch_bounds__(1024) void occ_scan_kernel(const int* __restrict__ 
 // position = queue start + tiles of heavier classes + object's start in the class + rank.  Block 0 also publishes the
 // queue boundaries.  (Positions inside a class depend on the order in which the setup blocks reserved their share:
 // the ORDER of items may differ between runs, the results cannot - every item writes only its own pixels.)
-__global__ __launch_bounds__(64) void occ_order_kernel(const int* __restrict__ objrect, const int* __restrict__ nrec,
-                                                       uint32_t* __restrict__ order, int n_env, int img) {
-    __shared__ uint32_t s_base[kOrdClasses];
-    const int eo = blockIdx.x, env = eo / 3, q = env & 7, lane = threadIdx.x;
+// (two halves around a block barrier: order_bases fills s_base - by the 64 lanes of ONE wave - order_items uses it)
+__device__ __forceinline__ void order_bases(uint32_t* __restrict__ order, uint32_t* s_base, int eo, int lane) {
+    const int env = eo / 3, q = env & 7;
     const uint32_t* counts = order + kOrdCounts;
     // queue totals: lane l < 8 sums queue l (32 loads; 256 words, L2-resident)
     uint32_t qt = 0u;
@@ -248,7 +247,9 @@ __global__ __launch_bounds__(64) void occ_order_kernel(const int* __restrict__ o
     }
     const uint32_t tot = (uint32_t)__shfl((int)incl, kOrdClasses - 1, 64);
     if (lane < kOrdClasses) s_base[lane] = qstart + (tot - incl) + order[kOrdBlk + (size_t)eo * kOrdClasses + lane];
-    __syncthreads();
+}
+__device__ __forceinline__ void order_items(const int* __restrict__ objrect, const int* __restrict__ nrec,
+                                            uint32_t* __restrict__ order, const uint32_t* s_base, int n_env, int img, int eo, int lane) {
     if (nrec[eo] <= 0) return;
     const int x0 = objrect[4 * eo], y0 = objrect[4 * eo + 1], x1 = objrect[4 * eo + 2], y1 = objrect[4 * eo + 3];
     if (x1 < x0 || y1 < y0 || x0 < 0 || y0 < 0) return;
@@ -263,4 +264,22 @@ __global__ __launch_bounds__(64) void occ_order_kernel(const int* __restrict__ o
         const uint32_t pos = s_base[w & 31u] + (w >> 5);
         if (pos < cap) items[pos] = make_uint2((uint32_t)eo, (uint32_t)local | (w & 31u) << 24);  // tile | cost class
     }
+}
+__global__ __launch_bounds__(64) void occ_order_kernel(const int* __restrict__ objrect, const int* __restrict__ nrec,
+                                                       uint32_t* __restrict__ order, int n_env, int img) {
+    __shared__ uint32_t s_base[kOrdClasses];
+    order_bases(order, s_base, blockIdx.x, threadIdx.x);
+    __syncthreads();
+    order_items(objrect, nrec, order, s_base, n_env, img, blockIdx.x, threadIdx.x);
+}
+// Round 5: ONE launch for the two small per-object passes between the setup and the raster kernel - the work-item order
+// (wave 0 of the block) and, for dense objects, the front-to-back sort of the scan rows (all 256 threads; occ_sort_kernel's
+// body) - instead of two dependent launches of ~5 us each.
+__global__ __launch_bounds__(256) void occ_sort_order_kernel(OccScene sc, OccWorkspace ws, int sort_cap) {
+    __shared__ uint32_t s_base[kOrdClasses];
+    const int eo = blockIdx.x, tid = threadIdx.x;
+    if (tid < 64) order_bases(ws.order, s_base, eo, tid);
+    __syncthreads();
+    if (tid < 64) order_items(ws.objrect, ws.nrec, ws.order, s_base, sc.n_env, sc.img, eo, tid);
+    if (sort_cap > 0) sort_object(sc, ws, sort_cap, eo);  // (a launch with sort_cap = 0 has 64 threads per block and no dynamic LDS)
 }

@@ -262,6 +262,21 @@ extern "C" int occ_step(const OccScene* scene, const OccCameraArgs* camera, floa
     // world-space vertices of an object staged in LDS when they fit (OccScene.max_mesh_verts; 0 = gather from global memory)
     int vcap = scene->max_mesh_verts > 0 ? ((scene->max_mesh_verts + 63) & ~63) : 0;
     if (vcap > kSetupVcapMax) vcap = kSetupVcapMax;
+    {   // the staged vertices come on top of the kernel's static LDS: never ask for more than the device gives a block
+        static int lds_room = -1;  // bytes of dynamic LDS occ_setup_kernel can have (queried once)
+        if (lds_room < 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            hipFuncAttributes fa;
+            lds_room = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&occ_setup_kernel<true, kSetupTB>)) == hipSuccess &&
+                prop.sharedMemPerBlock > fa.sharedSizeBytes)
+                lds_room = (int)(prop.sharedMemPerBlock - fa.sharedSizeBytes);
+        }
+        const int fit = (lds_room / 12) & ~63;
+        if (vcap > fit) vcap = fit;  // (0: gather from global memory, same results)
+    }
 #ifdef OCC_EXP_SETUP_DUMMY_LDS  // occupancy experiment only: the LDS is reserved but the vertices are still gathered from memory
     size_t vlds = (size_t)vcap * 3 * sizeof(float);
     vcap = 0;
@@ -273,11 +288,11 @@ extern "C" int occ_step(const OccScene* scene, const OccCameraArgs* camera, floa
     else
         hipLaunchKernelGGL((occ_setup_kernel<false, kSetupTB>), dim3(N * 3), dim3(kSetupTB), vlds, st, *scene, cam, wsv, vcap);
     OCC_DBG_SYNC("setup");
-    if (scene->rec_cap >= kSortMin) {
-        // dense objects only: front-to-back scan order (LDS sort buffer: 8192 keys = 64 KiB)
-        const int sort_cap = kSortCap;
-        hipLaunchKernelGGL(occ_sort_kernel, dim3(N * 3), dim3(256), (size_t)sort_cap * sizeof(unsigned long long), st,
-                           *scene, *ws, sort_cap);
+    const bool may_sort = scene->rec_cap >= kSortMin;  // dense objects only: front-to-back scan order (LDS sort buffer: 8192 keys = 64 KiB)
+    const int sort_cap = kSortCap;
+    const size_t sort_lds = may_sort ? (size_t)sort_cap * sizeof(unsigned long long) : 0;
+    if (may_sort && !wsv.order) {
+        hipLaunchKernelGGL(occ_sort_kernel, dim3(N * 3), dim3(256), sort_lds, st, *scene, *ws, sort_cap);
         OCC_DBG_SYNC("sort");
     }
     if (hipGetLastError() != hipSuccess) return OCC_ERR_LAUNCH;
@@ -296,7 +311,16 @@ extern "C" int occ_step(const OccScene* scene, const OccCameraArgs* camera, floa
         P.split_log2 = sl;
     }
     if (wsv.order) {
-        hipLaunchKernelGGL(occ_order_kernel, dim3(N * 3), dim3(64), 0, st, ws->objrect, ws->nrec, wsv.order, N, scene->img);
+        // (One launch for sort + order - occ_sort_order_kernel - was measured in round 5: 18.9 us against 5 + 5 for the two:
+        // the sort's 64 KB of LDS lets two blocks share a CU, and the order pass then runs at that occupancy.  It is used
+        // where no object can be dense - nothing to sort, no LDS.)
+        if (may_sort) {
+            hipLaunchKernelGGL(occ_sort_kernel, dim3(N * 3), dim3(256), sort_lds, st, *scene, *ws, sort_cap);
+            OCC_DBG_SYNC("sort");
+            hipLaunchKernelGGL(occ_order_kernel, dim3(N * 3), dim3(64), 0, st, ws->objrect, ws->nrec, wsv.order, N, scene->img);
+        } else {
+            hipLaunchKernelGGL(occ_sort_order_kernel, dim3(N * 3), dim3(64), 0, st, *scene, wsv, 0);
+        }
         OCC_DBG_SYNC("order");
     } else {
         hipLaunchKernelGGL(occ_scan_kernel, dim3(1), dim3(1024), 0, st, ws->objrect, ws->nrec, ws->offsets, N, 1);
@@ -443,6 +467,8 @@ extern "C" int occ_sigmoid_alpha_blend_bwd(const float* dists, const int64_t* pi
     return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
 }
 
+extern "C" int occ_ppo_max_blocks(void) { return OCC_PPO_MAX_BLOCKS; }
+
 extern "C" int occ_ppo_update(const float* feats, const float* actions, const float* old_logprob, const float* returns,
                               int64_t M, float action_var, float eps_clip, float lr_actor, float lr_critic, float beta1,
                               float beta2, float adam_eps, const OccPpoState* state, int n_epochs, float* losses,
@@ -524,17 +550,17 @@ extern "C" int occ_auto_reset(const uint8_t* done, const float* loss_all, const 
         !st->scene_mesh || !st->scene_offset || !store->obs || !store->full_state || !store->loss || !store->skip)
         return OCC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    StashArgs sa{rs_state, obs_all, full_state_all, loss_all, *store, img, n_env};
-    hipLaunchKernelGGL(occ_stash_kernel, dim3(n_reserve, kStashBlocks), dim3(256), 0, s, sa);
     OccAutoResetOpts o{};
     if (opts) o = *opts;
     if (o.max_ep_len > 0 && !o.age) return OCC_ERR_ARG;
     if (o.norm_flags && !o.slot_objsum) return OCC_ERR_ARG;
-    PairArgs pa{done, loss_all, status, n_env, n_reserve, rs_state, rs_tries, pairs, report, store->skip, o.age, o.max_ep_len};
+    int32_t* was_pending = pairs + 2 + 2 * n_reserve;  // third section of the scratch
+    PairArgs pa{done, loss_all, status, n_env, n_reserve, rs_state, rs_tries, pairs, report, store->skip, o.age, o.max_ep_len,
+                was_pending, o.report_host};
     hipLaunchKernelGGL(occ_pair_kernel, dim3(1), dim3(1024), 0, s, pa);
-    AutoCommitArgs ca{pairs, *st, obs_all, term_obs, store->obs, store->loss, img, n_env, o.age, o.rect, o.arect,
-                      store->full_state, o.reset_full_state, o.norm_flags, o.slot_objsum};
-    hipLaunchKernelGGL(occ_auto_commit_kernel, dim3(n_reserve, 1 + commit_obs_blocks(img) + commit_alpha_blocks(img)), dim3(256), 0, s, ca);
+    StashCommitArgs ca{was_pending, report + n_env + n_reserve, *st, obs_all, full_state_all, loss_all, *store, term_obs, img, n_env,
+                       o.age, o.rect, o.arect, o.reset_full_state, o.norm_flags, o.slot_objsum};
+    hipLaunchKernelGGL(occ_stash_commit_kernel, dim3(n_reserve, 1 + commit_obs_blocks(img) + commit_alpha_blocks(img)), dim3(256), 0, s, ca);
     return hipGetLastError() == hipSuccess ? OCC_OK : OCC_ERR_LAUNCH;
 }
 

@@ -99,11 +99,15 @@ struct WaveLog {
     uint2* __restrict__ kt;    // (order-preserving depth key, pixel of the tile 0..63 | face sequence number << 6)
     // Round 5: what the selection's LATER sweeps read.  Its first sweep (the first histogram pass) copies the entries of
     // the pixels that hold more than K candidates - 63 % of the log of a tile that needs selection on the bench - into
-    // this region, in log order: (key, pixel | low ten bits of the face sequence number << 6 | log index << 16).  The
-    // other histogram passes and the final sweep then visit those rows only.
+    // this region, in log order: (key, pixel | low twelve bits of the face sequence number << 6 | log index << 18).  The
+    // other histogram passes and the final sweep then visit those rows only.  (Twelve bits tell the faces of a 64-entry
+    // row apart as long as the row spans fewer than 4 096 faces; the copying pass checks that - a dense object's pruned
+    // log can be that sparse - and a tile that fails the check is swept in the log itself, as before round 5.)
     uint2* __restrict__ kt2;
 };
-static_assert(OCC_LOG_CAP <= 65536, "the compacted copy keeps the log index in sixteen bits");
+static_assert(OCC_LOG_CAP <= 16384, "the compacted copy keeps the log index in fourteen bits");
+constexpr uint32_t kSeqBitsB = 12;                       // bits of the face sequence number in a compacted entry
+constexpr uint32_t kSeqSpanB = (1u << kSeqBitsB) - 64u;  // faces a row of the compacted copy may span
 
 // Accumulator slot of pixel pix (= 8 py + px) in copy cpy.  A 16-byte LDS access is served 16 lanes at a time, one per
 // residue of the slot index mod 16: the column is rotated by 3 every second row and the copy stride is 1 mod 16, so that
@@ -323,6 +327,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             return a[0];
         };
 
+        int fseq_base = 0;  // faces staged before this batch: sequence number of a face in the tile = fseq_base + its slot
         // re-accumulated (prod (1 - p), sum g_el, sum g_az, count) of THIS lane's pixel when it went through selection
         float4 acc2 = make_float4(1.f, 0.f, 0.f, 0.f);
         // ---- exact top-K over the log for every pixel holding more than K entries ---------------------------
@@ -353,6 +358,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             // src / nsrc: what is swept - the log, or (final selection, after its first pass) the compacted copy
             const uint2* __restrict__ src = lg.kt;
             int nsrc = nlog;
+            bool fmt_b = false;  // the sweeps read the compacted copy (WaveLog.kt2) and its entry format
             auto load_group = [&](const int e0, auto& kt) __attribute__((always_inline)) {
                 constexpr int U = (int)(sizeof(kt) / sizeof(kt[0]));
 #pragma unroll
@@ -392,22 +398,42 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 // FINAL selection, first pass: the entries of the pixels under selection are also copied, in log order, to the
                 // compacted region that every later sweep reads (WaveLog.kt2)
                 int n2 = 0;
+                const unsigned long long ovf_m = __ballot(ovf);
+                const uint32_t ovf_lo = (uint32_t)ovf_m, ovf_hi = (uint32_t)(ovf_m >> 32);
+                const uint32_t L0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)L);  // (pass 0: L and sh are still the tile's, in every lane)
+                const uint32_t sh0 = (uint32_t)__builtin_amdgcn_readfirstlane(sh);
+                uint32_t row_first = 0u;  // lower bound of the face sequence numbers in the copy's open row (wave-uniform)
+                int n2_open = -1;         // that row
+                bool wide = false;        // some row of the copy may span too many faces for its twelve bits
                 auto bump_copy = [&](const int e0, const uint2 (&kt)[kSweepU]) __attribute__((always_inline)) {
 #pragma unroll
                     for (int u = 0; u < kSweepU; ++u) {
+                        // (first pass: every pixel under selection has the SAME window - the tile's - and which pixels those are is a
+                        // 64-bit mask: no window look-up in LDS, one dependent round trip less per group of rows)
                         bool ov = false;
                         if (kt[u].y != kNoEntry) {
                             const uint32_t px = kt[u].y & 63u;
-                            const uint2 w = s_sel[px];
-                            if (w.y < 32u) {
-                                ov = true;
-                                const uint32_t d = (kt[u].x - w.x) >> w.y;
-                                if (kt[u].x >= w.x && d < (1u << kSelBits)) atomicAdd(&hist[px * kSelStride + (d >> 1)], 1u << (16 * (d & 1u)));
+                            ov = (((px & 32u) ? ovf_hi : ovf_lo) >> (px & 31u)) & 1u;
+                            if (ov) {
+                                const uint32_t d = (kt[u].x - L0) >> sh0;
+                                if (kt[u].x >= L0 && d < (1u << kSelBits)) atomicAdd(&hist[px * kSelStride + (d >> 1)], 1u << (16 * (d & 1u)));
                             }
                         }
                         const unsigned long long m = __ballot(ov);
-                        if (ov) lg.kt2[n2 + lane_rank(m)] = make_uint2(kt[u].x, (kt[u].y & 0xFFFFu) | (uint32_t)(e0 + u * 64 + lane) << 16);
+                        if (ov) lg.kt2[n2 + lane_rank(m)] = make_uint2(kt[u].x, (kt[u].y & ((64u << kSeqBitsB) - 1u)) | (uint32_t)(e0 + u * 64 + lane) << (6 + kSeqBitsB));
                         n2 += __popcll(m);
+                    }
+                    // The span of the copy's 64-entry rows, bounded per GROUP of log rows (face sequence numbers do not decrease
+                    // along the log): the row that was open when the group began reaches at most the group's last face; a row
+                    // opened inside the group starts no earlier than the group's first.  (Per ballot and exact, with two more
+                    // ballots and a branch, this check cost the kernel 25 %: it serialises the group's four rows.)
+                    const uint32_t g_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(kt[0].y >> 6));
+                    const uint32_t g_last = e0 + kGroup <= nsrc ? (uint32_t)__builtin_amdgcn_readlane((int)(kt[kSweepU - 1].y >> 6), 63) : (uint32_t)fseq_base;
+                    if (n2_open < 0) row_first = g_first;  // (the very first row)
+                    wide = wide || (n2 > 0 && g_last - row_first >= kSeqSpanB);
+                    if ((n2 >> 6) != n2_open) {
+                        row_first = g_first;
+                        n2_open = n2 >> 6;
                     }
                 };
                 {
@@ -424,10 +450,11 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                         }
                     }
                 }
-                if (!compact && pass == 0) {
+                if (!compact && pass == 0 && !wide) {
                     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the copy is in memory before it is swept
                     src = lg.kt2;
                     nsrc = n2;
+                    fmt_b = true;
                     OCC_STAT(13, n2);  // entries in the compacted copy
                 }
                 pass += 1;
@@ -595,9 +622,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #pragma unroll
                     for (int u = 0; u < kSweepU; ++u) {
                         const bool act = (ptag[u] >> 31) != 0u;
-                        const uint32_t tag = ptag[u] & 0xFFFFu;
-                        // (ten bits of the face sequence number: a 64-entry row spans fewer than 64 faces, the groups of four
-                        // consecutive faces inside it are told apart by their low bits)
+                        const uint32_t tag = ptag[u] & 0x7FFFFFFFu;  // pixel | face sequence number << 6 (all of it, or its low twelve bits)
                         const uint32_t grp = tag >> (6 + kCopyBits);
                         const int slot = acc_slot((int)((tag >> 6) & (uint32_t)(kCopies - 1)), (int)(tag & 63u));
                         unsigned long long rem = __ballot(act);
@@ -624,7 +649,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                         }
                     }
                 };
-                auto decide = [&](const uint2 (&kt)[kSweepU]) __attribute__((always_inline)) {
+                auto decide = [&](const int e0, const uint2 (&kt)[kSweepU]) __attribute__((always_inline)) {
                     uint32_t readdm = 0u;
 #pragma unroll
                     for (int u = 0; u < kSweepU; ++u) {  // decisions in log order (ties are served first come)
@@ -639,7 +664,8 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                                 } else if (((kt[u].x - w.x) >> shp) == 0u) {
                                     if ((w.y >> 8) == (uint32_t)kList) {
                                         const uint32_t sl = atomicAdd(&s_lcnt[px], 1u);
-                                        if (sl < (uint32_t)kListCap) blist[px * kListCap + sl] = make_uint2(kt[u].x, kt[u].y >> 16);  // (key, log index)
+                                        if (sl < (uint32_t)kListCap)  // (key, log index)
+                                            blist[px * kListCap + sl] = make_uint2(kt[u].x, fmt_b ? kt[u].y >> (6 + kSeqBitsB) : (uint32_t)(e0 + u * 64 + lane));
                                     } else {
                                         r = (int)atomicSub(&s_take[px], 1u) > 0;  // the first `take` arrivals are kept
                                     }
@@ -651,8 +677,9 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #pragma unroll
                     for (int u = 0; u < kSweepU; ++u) {
                         const bool r = (readdm >> u) & 1u;
-                        const uint32_t e = kt[u].y >> 16;  // index of the entry in the log itself: where its payload is
-                        ptag[u] = r ? ((kt[u].y & 0xFFFFu) | 0x80000000u) : 0u;
+                        // index of the entry in the log itself (where its payload is), and its tag without that index
+                        const uint32_t e = fmt_b ? kt[u].y >> (6 + kSeqBitsB) : (uint32_t)(e0 + u * 64 + lane);
+                        ptag[u] = r ? ((fmt_b ? kt[u].y & ((64u << kSeqBitsB) - 1u) : kt[u].y) | 0x80000000u) : 0u;
 #ifdef OCC_EXP_FS_NO_PAY  // timing experiment only (results void): what the final sweep's dependent payload loads cost
                         ppay[u] = LogPay{__uint_as_float(0x3f800000u | (r ? 1u : 0u)), 0.f, (float)e};
 #else
@@ -664,7 +691,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #pragma unroll
                     for (int gi = 0; gi < kRingG; ++gi) {
                         apply();  // the group before this one
-                        decide(ring[gi]);
+                        decide(e0 + gi * kGroup, ring[gi]);
                         load_group(e0 + (kRingG + gi) * kGroup, ring[gi]);
                     }
                 }
@@ -788,7 +815,6 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 
         // ---- one staged batch: records -> LDS, pair expansion, evaluation rounds ------------------------------
         int nst = 0;  // staged faces (wave-uniform)
-        int fseq_base = 0;  // faces staged before this batch: sequence number of a face in the tile = fseq_base + its slot
         // records of the staged faces -> LDS (part-major).  Lane i of a group of 8 fetches part i of one record: the 8
         // loads of a record are one 128-byte line.  kStg2 * 8 / 64 = 4 loads per lane, issued together.
         constexpr int kStageLoads = kStg2 * kRecParts / 64;

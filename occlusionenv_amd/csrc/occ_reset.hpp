@@ -9,6 +9,8 @@ struct PairArgs {
     int n_env, n_res;
     int* rs_state; int* rs_tries; int* pairs; int* report; int* skip;
     int* age; int max_ep_len;  // episode time limit (trainRL.py:22,191-229): age (n_env) counts the steps since the last reset
+    int* was_pending;          // (n_res) out: the slot was under test, i.e. rendered by this step's launch (occ_stash_commit_kernel)
+    int* report_host;          // second copy of the report in pinned host memory (no copy launch), or null
 };
 
 // ordered compaction helper: exclusive prefix of flag over a 1024-thread block (16 waves)
@@ -41,6 +43,7 @@ __global__ __launch_bounds__(1024) void occ_pair_kernel(PairArgs a) {
     int st = OCC_RS_EMPTY;
     if (tid < R) {
         st = a.rs_state[tid];
+        a.was_pending[tid] = st == OCC_RS_PENDING ? 1 : 0;
         if (st == OCC_RS_PENDING) {
             const int t = a.rs_tries[tid] + 1;
             // accept, or keep the 10th try regardless (environment.py:288,327)
@@ -48,6 +51,7 @@ __global__ __launch_bounds__(1024) void occ_pair_kernel(PairArgs a) {
             a.rs_tries[tid] = t;
         }
         a.report[N + R + tid] = -1;
+        if (a.report_host) a.report_host[N + R + tid] = -1;
     }
     int nready;
     const int rpos = block_prefix_1024(tid < R && st == OCC_RS_READY, s_w, tid, nready);
@@ -68,6 +72,8 @@ __global__ __launch_bounds__(1024) void occ_pair_kernel(PairArgs a) {
         const bool f = fin || expired;
         if (i < N) {
             a.report[i] = fin ? 1 : (expired ? 2 : 0);
+            // (the host hands over its copy with this section zeroed: only the few envs that were reset are written across the bus)
+            if (a.report_host && f) a.report_host[i] = fin ? 1 : 2;
             any |= a.status[i];
         }
         int tot;
@@ -85,6 +91,7 @@ __global__ __launch_bounds__(1024) void occ_pair_kernel(PairArgs a) {
         a.pairs[2 + 2 * tid] = i;
         a.pairs[3 + 2 * tid] = N + r;
         a.report[N + R + r] = i;
+        if (a.report_host) a.report_host[N + R + r] = i;
     }
     // a READY slot that was taken goes back to EMPTY with a fresh try count
     const bool taken = tid < R && st == OCC_RS_READY && rpos < npair;
@@ -95,70 +102,69 @@ __global__ __launch_bounds__(1024) void occ_pair_kernel(PairArgs a) {
         }
         a.rs_state[tid] = st;
         a.report[N + tid] = st;
+        if (a.report_host) a.report_host[N + tid] = st;
         a.skip[N + tid] = (st != OCC_RS_PENDING) ? 1 : 0;  // only slots under test are rendered by the next step
     }
     if (tid == 0) {
         a.pairs[0] = npair;
         a.report[N + 2 * R] = s_any;
         a.report[N + 2 * R + 1] = nfin - npair;
+        if (a.report_host) {
+            a.report_host[N + 2 * R] = s_any;
+            a.report_host[N + 2 * R + 1] = nfin - npair;
+        }
     }
+    // (the host reads report_host after the event that follows this call's last launch: the kernel boundary makes the stores visible)
 }
 
-// rows this step rendered for PENDING slots -> persistent store (runs BEFORE the pairing changes any state)
-struct StashArgs {
-    const int* rs_state; const float* obs_all; const float* fs_all; const float* loss_all;
-    OccReserveStore store;
-    int img, n_env;
-};
-constexpr int kStashBlocks = 64;  // (16: one stash of ~14 slots took 14 us, four dependent load-store rounds per thread)
-__global__ __launch_bounds__(256) void occ_stash_kernel(StashArgs a) {
-    const int r = blockIdx.x;
-    if (a.rs_state[r] != OCC_RS_PENDING) return;
-    const int tid = threadIdx.x, y = blockIdx.y;
-    const size_t S2 = (size_t)a.img * a.img, src = (size_t)(a.n_env + r);
-    const float4* o4 = reinterpret_cast<const float4*>(a.obs_all + src * 4 * S2);
-    const float4* f4 = reinterpret_cast<const float4*>(a.fs_all + src * 4 * S2);
-    float4* od = reinterpret_cast<float4*>(a.store.obs + (size_t)r * 4 * S2);
-    float4* fd = reinterpret_cast<float4*>(a.store.full_state + (size_t)r * 4 * S2);
-    for (size_t i = (size_t)y * 256 + tid; i < S2; i += (size_t)kStashBlocks * 256) {
-        od[i] = o4[i];
-        fd[i] = f4[i];
-    }
-    if (y == 0 && tid == 0) a.store.loss[r] = a.loss_all[src];
-}
-
-struct AutoCommitArgs {
-    const int* pairs;
+// One launch after the pairing (round 5; until then occ_stash_kernel BEFORE and occ_auto_commit_kernel AFTER it), one block
+// group per reserve slot r:
+//   * the slot was under test in this step (was_pending) and nobody takes it: its rendered rows (observation, occlusion
+//     image, loss) go to the persistent store - a READY slot is not rendered again;
+//   * an env takes the slot (slot_env[r] >= 0): the env's final observation goes to term_obs[r]
+//     (info["terminal_observation"]), the slot's render - straight from this step's rows if it was rendered just now,
+//     else from the store - and state become the env's (environment.py:302-324), the stored occlusion image goes to
+//     reset_fs[r].
+struct StashCommitArgs {
+    const int* was_pending;  // (n_res)
+    const int* slot_env;     // (n_res) env that takes the slot in this call or -1 (the report's third section)
     OccEnvState st;
-    float* obs_all; float* term_obs; const float* res_obs; const float* res_loss;
+    float* obs_all; const float* fs_all; const float* loss_all;
+    OccReserveStore store;
+    float* term_obs;
     int img, n_env;
     int* age;                  // (n_env) or null: zeroed for the env that takes a slot
     int* rect; int* arect;     // region-tracking rects of obs_all / the alphas state or null: the committed row is a full frame
-    const float* res_fs; float* reset_fs;  // stored occlusion image of the slot -> reset_fs[slot] (the env's image after reset) or null
+    float* reset_fs;           // (n_res,S,S,4) or null
     const int* norm_flags; const float* slot_objsum;  // normWithObjectSize (environment.py:324) or null
 };
 // grid.y = 1 (state) + obs_blocks + alpha_blocks: the copies are sized by the image - a block moves ~4 x 256 float4 per
-// plane it touches (with the 8 + 6 blocks that were enough at 128 x 128 the commit of ONE env took 40 us at 256 x 256,
-// 128 serial scalar iterations per thread in the alpha part)
+// plane it touches
 __host__ __device__ inline int commit_obs_blocks(int img) { return max(1, (img * img) / 256); }   // one float4 per thread and array
 __host__ __device__ inline int commit_alpha_blocks(int img) { return max(1, (3 * img * img) / 1024); }
-__global__ __launch_bounds__(256) void occ_auto_commit_kernel(AutoCommitArgs a) {
-    const int k = blockIdx.x;
-    if (k >= a.pairs[0]) return;
-    const int dst = a.pairs[2 + 2 * k], src = a.pairs[3 + 2 * k];
+__global__ __launch_bounds__(256) void occ_stash_commit_kernel(StashCommitArgs a) {
+    const int r = blockIdx.x;
+    const bool pend = a.was_pending[r] != 0;
+    const int dst = a.slot_env[r];
+    if (!pend && dst < 0) return;
+    const int src = a.n_env + r;
     const int tid = threadIdx.x, y = blockIdx.y;
     const size_t S2 = (size_t)a.img * a.img;
     const int obs_blocks = commit_obs_blocks(a.img), alpha_blocks = commit_alpha_blocks(a.img);
     if (y == 0) {
+        const float l = pend ? a.loss_all[src] : a.store.loss[r];
+        if (dst < 0) {
+            if (tid == 0) a.store.loss[r] = l;
+            return;
+        }
         if (tid == 0) {
             a.st.el[dst] = a.st.el[src];
             a.st.az[dst] = a.st.az[src];
             a.st.radius[dst] = a.st.radius[src];
-            const float l = a.res_loss[src - a.n_env];
             a.st.full_reward[dst] = l;
             // environment.py:324: objectMass = sum(objects^2) + 1 if normWithObjectSize else loss + 1
             const bool norm = a.norm_flags && a.norm_flags[dst] != 0;
-            a.st.object_mass[dst] = (norm ? a.slot_objsum[src - a.n_env] : l) + 1.0f;
+            a.st.object_mass[dst] = (norm ? a.slot_objsum[r] : l) + 1.0f;
         }
         if (tid < 3) {
             a.st.campos[dst * 3 + tid] = 0.f;
@@ -173,18 +179,27 @@ __global__ __launch_bounds__(256) void occ_auto_commit_kernel(AutoCommitArgs a) 
             if (a.arect) a.arect[dst * 4 + tid] = full;
         }
     } else if (y <= obs_blocks) {
-        // final observation -> term_obs[slot], stored reset observation -> obs[env] (same element range, same thread)
-        const float4* s4 = reinterpret_cast<const float4*>(a.res_obs + (size_t)(src - a.n_env) * 4 * S2);
-        float4* d4 = reinterpret_cast<float4*>(a.obs_all + (size_t)dst * 4 * S2);
-        float4* t4 = reinterpret_cast<float4*>(a.term_obs + (size_t)(src - a.n_env) * 4 * S2);
-        const float4* f4 = a.reset_fs ? reinterpret_cast<const float4*>(a.res_fs + (size_t)(src - a.n_env) * 4 * S2) : nullptr;
-        float4* g4 = a.reset_fs ? reinterpret_cast<float4*>(a.reset_fs + (size_t)(src - a.n_env) * 4 * S2) : nullptr;
-        for (size_t i = (size_t)(y - 1) * 256 + tid; i < S2; i += (size_t)obs_blocks * 256) {
-            t4[i] = d4[i];
-            d4[i] = s4[i];
-            if (f4) g4[i] = f4[i];
+        // what the slot's last render produced: this step's rows if it was rendered just now, else the store
+        const float4* o4 = reinterpret_cast<const float4*>(pend ? a.obs_all + (size_t)src * 4 * S2 : a.store.obs + (size_t)r * 4 * S2);
+        const float4* f4 = reinterpret_cast<const float4*>(pend ? a.fs_all + (size_t)src * 4 * S2 : a.store.full_state + (size_t)r * 4 * S2);
+        if (dst < 0) {  // stash
+            float4* od = reinterpret_cast<float4*>(a.store.obs + (size_t)r * 4 * S2);
+            float4* fd = reinterpret_cast<float4*>(a.store.full_state + (size_t)r * 4 * S2);
+            for (size_t i = (size_t)(y - 1) * 256 + tid; i < S2; i += (size_t)obs_blocks * 256) {
+                od[i] = o4[i];
+                fd[i] = f4[i];
+            }
+        } else {  // commit: final observation -> term_obs[slot], reset observation -> obs[env] (same element range, same thread)
+            float4* d4 = reinterpret_cast<float4*>(a.obs_all + (size_t)dst * 4 * S2);
+            float4* t4 = reinterpret_cast<float4*>(a.term_obs + (size_t)r * 4 * S2);
+            float4* g4 = a.reset_fs ? reinterpret_cast<float4*>(a.reset_fs + (size_t)r * 4 * S2) : nullptr;
+            for (size_t i = (size_t)(y - 1) * 256 + tid; i < S2; i += (size_t)obs_blocks * 256) {
+                t4[i] = d4[i];
+                d4[i] = o4[i];
+                if (g4) g4[i] = f4[i];
+            }
         }
-    } else {
+    } else if (dst >= 0) {
         // (img is a multiple of 8: the three alpha planes are a whole number of float4)
         const float4* s4 = reinterpret_cast<const float4*>(a.st.alphas + (size_t)src * 3 * S2);
         float4* d4 = reinterpret_cast<float4*>(a.st.alphas + (size_t)dst * 3 * S2);

@@ -337,9 +337,9 @@ constexpr int kSortMin = OCC_SORT_MIN;
 constexpr int kSortCap = 8192;  // records of one object that the sort kernel's LDS holds (64 KiB of keys)
 // an object whose scan order occ_sort_kernel has re-sorted: its sorted rows are in OccWorkspace.rec_bbox
 __host__ __device__ __forceinline__ bool scan_is_sorted(int nrec) { return nrec >= kSortMin && nrec <= kSortCap; }
-__global__ __launch_bounds__(256) void occ_sort_kernel(OccScene sc, OccWorkspace ws, int sort_cap) {
+// (256 threads of one block; every thread of the block returns together before the first barrier when there is nothing to sort)
+__device__ __forceinline__ void sort_object(const OccScene& sc, const OccWorkspace& ws, int sort_cap, int eo) {
     extern __shared__ unsigned long long s_keys[];  // sort_cap keys: depth key << 32 | record index
-    const int eo = blockIdx.x;
     const int nr = ws.nrec[eo];
     if (!scan_is_sorted(nr) || sort_cap < kSortCap) return;
     int p2 = 1;
@@ -374,6 +374,9 @@ __global__ __launch_bounds__(256) void occ_sort_kernel(OccScene sc, OccWorkspace
     }
     __syncthreads();
     chunk_boxes(sorted, reinterpret_cast<uint4*>(ws.rec_cbox) + span.cbox, nr, wave, lane);
+}
+__global__ __launch_bounds__(256) void occ_sort_kernel(OccScene sc, OccWorkspace ws, int sort_cap) {
+    sort_object(sc, ws, sort_cap, blockIdx.x);
 }
 
 constexpr int kSetupVcapMax = 4096;  // vertices of one object that the setup kernel stages in LDS (48 KB) at most

@@ -153,9 +153,10 @@ class OcclusionEngine:
             i32 = dict(dtype=torch.int32, device=d)
             self.rs_state = torch.zeros(self.R, **i32)   # OCC_RS_EMPTY
             self.rs_tries = torch.zeros(self.R, **i32)
-            self._pairs = torch.zeros(2 + 2 * self.R, **i32)
-            self._refill_dev = torch.zeros(self.R, 13, **i32)
-            self._refill_host = [torch.zeros(self.R, 13, dtype=torch.int32).pin_memory() for _ in range(2)]
+            self._pairs = torch.zeros(2 + 3 * self.R, **i32)
+            # pinned rows the refill kernel reads in place; four buffers in turn (a step refills at most twice, and the host
+            # waits for the step's report event - later on the stream than those kernels - before the next step's refills)
+            self._refill_host = [torch.zeros(self.R, 13, dtype=torch.int32).pin_memory() for _ in range(4)]
             self._report_host = [torch.zeros(N + 2 * self.R + 2, dtype=torch.int32).pin_memory() for _ in range(2)]
             self._flip = 0
             # what the last render of every slot produced: a slot is rendered only while PENDING (skip mask), a
@@ -593,14 +594,15 @@ class OcclusionEngine:
         self._rs_mesh_host.numpy()[sl] = m
         self._rs_off_host.numpy()[sl] = off.reshape(n, 3, 3)
         self._put_mesh_rows(self.N + sl, m)
-        self._flip ^= 1
+        self._flip = (self._flip + 1) % len(self._refill_host)
         host = self._refill_host[self._flip]
         h = host.numpy()
         h[:n, 0] = sl
         h[:n, 1:4] = m
         h[:n, 4:13] = off.view(np.int32)
-        self._refill_dev[:n].copy_(host[:n], non_blocking=True)
-        nat.check(self.lib.occ_reserve_refill(_p(self._refill_dev), n, self.N, self.R, _p(self._mesh_all), _p(self._off_all),
+        # the kernel reads the rows straight from the pinned buffer when it runs (no copy launch): the buffers alternate, and
+        # before this one is written again the host has waited for a later event on the stream (the next step's report)
+        nat.check(self.lib.occ_reserve_refill(C.c_void_p(host.data_ptr()), n, self.N, self.R, _p(self._mesh_all), _p(self._off_all),
                                               _p(self.rs_state), _p(self._skip), self._stream()), "occ_reserve_refill")
 
     def auto_reset(self, out) -> dict:
@@ -629,13 +631,15 @@ class OcclusionEngine:
         store = nat.OccReserveStore()
         store.obs, store.full_state, store.loss = self._res_obs.data_ptr(), self._res_fs.data_ptr(), self._res_loss.data_ptr()
         store.skip = self._skip.data_ptr()
+        # the pairing launch writes the report into pinned host memory itself (no copy launch); two buffers alternate
+        self._rflip = getattr(self, "_rflip", 0) ^ 1
+        host = self._report_host[self._rflip]
+        host.numpy()[:N] = 0  # the kernel writes only the entries of the envs it resets (last read two steps ago)
+        opts.report_host = host.data_ptr()
         nat.check(self.lib.occ_auto_reset(_p(out["done_u8"]), _p(out["loss_all"]), _p(self.status), N, R, _p(self.rs_state),
                                           _p(self.rs_tries), C.byref(st), _p(out["obs_all"]), _p(out["full_state_all"]),
                                           C.byref(store), _p(term), S, _p(self._pairs), _p(report), C.byref(opts), self._stream()),
                   "occ_auto_reset")
-        self._rflip = getattr(self, "_rflip", 0) ^ 1
-        host = self._report_host[self._rflip]
-        host.copy_(report, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         return dict(report_host=host, event=ev, term=term, report=report, reset_fs=reset_fs)

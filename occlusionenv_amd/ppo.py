@@ -122,7 +122,7 @@ class BatchedPPO:
             dev = next(self.policy.parameters()).device
             f32 = dict(dtype=torch.float32, device=dev)
             self._fused_state = dict(m=torch.zeros(nat.PPO_PARAMS, **f32), v=torch.zeros(nat.PPO_PARAMS, **f32),
-                                     step=torch.zeros(1, **f32), scratch=torch.empty(nat.PPO_SCRATCH_FLOATS, **f32),
+                                     step=torch.zeros(1, **f32), scratch=torch.empty(nat.ppo_scratch_floats(), **f32),
                                      counter=torch.zeros(1, dtype=torch.int32, device=dev))
         self.records = []  # list of (N_total, 261) tensors, one per step
 

@@ -9,6 +9,10 @@ ROOTD=$PWD
 OUT=$ROOTD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+# rocprofv3 (with --pmc) initialises the GPU in the process it starts: what follows `--` must be the interpreter itself - an
+# ELF binary - not a pyenv / conda shim or wrapper script that would exec again (forbidden on this pool once the GPU is open)
+PY=$(readlink -f "$(command -v python)")
+if [ "$(head -c 4 "$PY" | tail -c 3)" != "ELF" ]; then echo "python resolves to $PY, which is not an ELF binary: refusing to profile through a wrapper" >&2; exit 3; fi
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS" \
@@ -16,7 +20,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  (cd /tmp && timeout -k 10 240 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/p$i" -- python "$ROOTD/bench.py" --steps 6 --warmup 2 --no-cpu-baseline "$@" > "$OUT/p$i.log" 2>&1)
+  (cd /tmp && timeout -k 10 240 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/p$i" -- "$PY" "$ROOTD/bench.py" --steps 6 --warmup 2 --no-cpu-baseline "$@" > "$OUT/p$i.log" 2>&1)
   echo "pmc pass $i rc $?"
 done
 python - "$OUT" <<'PY'

@@ -10,7 +10,11 @@ What is recorded is what the reference computed, nothing restated here:
   * ``policy.evaluate(old_states, old_actions)`` (PPO.py:82-104) before the update;
   * inside ``update()`` (PPO.py:176-223), per K in {1, 5, 80}: the normalised returns and every epoch's value loss
     (captured by wrapping ``ppo.MseLoss``, which update() calls with (state_values, rewards)), and the resulting
-    action_head / value_head parameters.
+    action_head / value_head parameters;
+  * for K = 80 the same ``update()`` once more with the two heads, the buffer and the action variance converted to
+    float64 (``.double()``; every line executed is still the reference's): the DOUBLE-PRECISION trajectory's heads,
+    ``<scen>_final64_<head>_K80`` - the arbiter of how far an f32 implementation may drift over 80 epochs through the
+    clip boundary of PPO.py:207 (tests/test_ppo_golden.py).
 The reference never travels to the GPU box; only the .npz does.
 """
 import os
@@ -76,6 +80,8 @@ def main():
         direct = torch.randn(T, 256, generator=g).abs()
         for scen, K in [(s, k) for s in ("enc", "dir") for k in (1, 5, 80)]:
             _run(out, scen, K, make, obs, direct, rewards, terminals)
+        for scen in ("enc", "dir"):
+            _run(out, scen, 80, make, obs, direct, rewards, terminals, f64=True)
         out["hyper"] = np.array(repr(dict(HYPER, T=T, obs_side=S)))
         os.chdir(HERE)
     np.savez_compressed(os.path.join(HERE, "ppo_golden.npz"), **out)
@@ -87,8 +93,9 @@ def _heads(policy):
     return dict(w_a=net.action_head.weight, b_a=net.action_head.bias, w_v=net.value_head.weight, b_v=net.value_head.bias)
 
 
-def _run(out, scen, K, make, obs, direct, rewards, terminals):
-    """One reference agent: fill its buffer, evaluate(), update(); everything lands in `out` under `<scen>_...`."""
+def _run(out, scen, K, make, obs, direct, rewards, terminals, f64=False):
+    """One reference agent: fill its buffer, evaluate(), update(); everything lands in `out` under `<scen>_...`.
+    ``f64``: the update runs on float64 copies of the heads / buffer (same f32 inputs); only the final heads are recorded."""
     agent = make(K)
     agent.policy.eval(), agent.policy_old.eval()
     torch.manual_seed(99)  # the sampling noise of the old policy: the same buffer for every K
@@ -117,6 +124,26 @@ def _run(out, scen, K, make, obs, direct, rewards, terminals):
         if f"{scen}_{k}" in out:  # same weights, same noise: the same buffer for every K
             assert np.array_equal(out[f"{scen}_{k}"], v), k
         out[f"{scen}_{k}"] = v
+    if f64:
+        for pol in (agent.policy, agent.policy_old):
+            pol.model.action_head.double()
+            pol.model.value_head.double()
+            pol.action_var = pol.action_var.double()
+        agent.buffer.states = [x.double() for x in agent.buffer.states]
+        agent.buffer.actions = [x.double() for x in agent.buffer.actions]
+        agent.buffer.logprobs = [x.double() for x in agent.buffer.logprobs]
+        agent.buffer.rewards = [x.double() for x in agent.buffer.rewards]
+
+        class _Mse64(torch.nn.Module):  # update() builds its returns as float32 (PPO.py:187): MSELoss wants one dtype
+            def forward(self, values, returns):
+                return torch.nn.functional.mse_loss(values, returns.to(values.dtype))
+
+        agent.MseLoss = _Mse64()
+        agent.update()
+        for k, v in _heads(agent.policy).items():
+            assert v.dtype == torch.float64
+            out[f"{scen}_final64_{k}_K{K}"] = v.detach().clone().numpy()
+        return
     spy = _Spy()
     agent.MseLoss = spy
     agent.update()

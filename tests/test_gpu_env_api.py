@@ -480,6 +480,94 @@ def test_record_arrays_follow_the_scenes_not_the_largest_mesh():
     assert torch.isfinite(loss).all() and float(eng.alphas[5, 1].max()) > 0.5  # the big object is there
 
 
+def test_batched_512_reference_default_size():
+    """img_size = 512 is the reference's default and what trainRL.py runs (environment.py:202, trainRL.py:75); here it is
+    BATCHED: 64 envs x 512 x 512, three 5 120-face objects each.  Workspace sizes as occ_workspace_query lays them out,
+    the same size-independent properties as the 128 x 128 full-size test, batched == single env bitwise, and the batched
+    VecEnv path (reserve, recycled outputs, auto-reset) at this size."""
+    import ctypes as C
+
+    from environment import OcclusionEnv
+    from SubProcVecEnv import SimpleVecEnv
+    from occlusionenv_amd import _native as nat
+    from occlusionenv_amd.engine import OcclusionEngine
+    from occlusionenv_amd.meshes import SyntheticShapeNet
+    from tests.parity_utils import make_case
+
+    N, S = 64, 512
+    case = make_case(N, 23, "synthetic")
+    eng = OcclusionEngine(case["pool"], N, S)
+    eng.set_scene(list(range(N)), case["mesh_ids"], case["offsets"])
+    obs0, loss0, fs0 = eng.reset_render(None, 4.0, case["az"], 0.0)
+    fr0, om = eng.full_reward.clone(), eng.object_mass.clone()
+    a = case["actions"].cuda().requires_grad_(True)
+    obs, reward, done, fs, loss = eng.step(a)
+    reward.sum().backward()
+    eng.check_status()
+    # workspace: what occ_workspace_query says for (N, S), byte for byte
+    sizes = nat.OccWorkspaceSizes()
+    sc = eng._scene_struct(N, eng._mesh_all, eng._off_all)
+    n_slots = eng.lib.occ_device_cu_count() * eng.waves_per_cu
+    nat.check(eng.lib.occ_workspace_query(C.byref(sc), n_slots, C.byref(sizes)), "query")
+    S2 = S * S
+    assert sizes.obj_alpha_bytes == N * 3 * S2 * 4 and sizes.obj_grad_bytes == N * 3 * S2 * 8 and sizes.obj_hrec_bytes == N * 3 * S2 * 4
+    assert sizes.partials_bytes == N * (S2 // 256) * 16 and sizes.lists_bytes == n_slots * nat.LOG_CAP * nat.LOG_ENTRY_BYTES
+    T = (S // 8) ** 2
+    assert sizes.order_bytes >= (N * 3 * T * 3) * 4  # per-tile (rank, class) words + 8-byte items
+    for k in ("obj_alpha", "obj_grad", "obj_hz", "obj_hrec", "partials", "lists", "order"):
+        assert eng._ws_tensors[k].numel() * 4 >= getattr(sizes, k + "_bytes"), k
+    assert eng._rec_total >= N * 3 * 2 * 5120 and eng._rec_total < 2 * N * 3 * 2 * 5120  # records follow the scenes
+    # properties
+    al = eng.alphas
+    assert float(al.min()) >= 0.0 and float(al.max()) <= 1.0
+    I = al[:, 0] * al[:, 1] + al[:, 1] * al[:, 2] + al[:, 0] * al[:, 2]
+    assert torch.allclose(fs[..., 3], I, atol=1e-6) and bool((fs[..., :3] == 3).all())
+    assert torch.allclose(loss, (fs[..., 3].double() ** 2).sum((1, 2)).float(), rtol=1e-4, atol=1e-3)
+    bg = obs[:, 3] == -1.0
+    assert bool((obs[:, :3].permute(0, 2, 3, 1)[bg] == 1.0).all()) and float(obs[:, 3][~bg].min()) > 0.5
+    exp = (fr0 - loss) / om + torch.where(loss < 0.1, torch.tensor(5.0, device="cuda"), torch.tensor(-0.2, device="cuda"))
+    assert torch.allclose(reward.detach(), exp, atol=1e-5) and torch.equal(done, loss < 0.1)
+    assert torch.isfinite(a.grad).all() and float(a.grad.abs().max()) > 0
+    rect = eng._ws_tensors["objrect"][: 4 * 3 * N].view(-1, 4)
+    vis = eng._ws_tensors["nrec"][: 3 * N] > 0
+    assert int(rect[vis].min()) >= 0 and int(rect[vis].max()) < S // 4
+    # batched == one env at a time, bitwise (two envs)
+    for i in (3, 40):
+        e1 = OcclusionEngine(case["pool"], 1, S)
+        e1.set_scene([0], case["mesh_ids"][i:i + 1], case["offsets"][i:i + 1])
+        e1.reset_render(None, 4.0, case["az"][i:i + 1], 0.0)
+        a1 = case["actions"][i:i + 1].cuda().requires_grad_(True)
+        o1, r1, d1, f1, l1 = e1.step(a1)
+        r1.sum().backward()
+        assert torch.equal(o1[0], obs[i]) and torch.equal(f1[0], fs[i]) and torch.equal(r1.detach()[0], reward.detach()[i])
+        assert torch.equal(a1.grad[0], a.grad[i])
+        del e1
+    del eng, obs, fs, obs0, fs0
+    torch.cuda.empty_cache()
+    # the VecEnv path at this size: reserve of 16 scenes, recycled outputs, a forced auto-reset
+    ds512 = SyntheticShapeNet(n_models=8, seed=1234)
+    venv = SimpleVecEnv([lambda: OcclusionEnv(ds512, img_size=S) for _ in range(N)])
+    venv._reset_envs(list(range(N)), torch.zeros(N))
+    venv._warm_reserve()
+    e2 = venv.engine
+    assert e2.R == 16 and e2.output_recycle >= 2
+    off = e2.scene_offset[9].clone()
+    off[1, 0], off[2, 0] = 50.0, -50.0
+    e2.scene_offset[9] = off
+    ptrs = set()
+    for t in range(4):
+        act = torch.randn(N, 2, device="cuda", requires_grad=True)
+        o, r, d, infos = venv.step(act)
+        r.sum().backward()
+        ptrs.add(o.data_ptr())
+        assert o.shape == (N, 4, S, S) and torch.isfinite(r).all() and torch.isfinite(act.grad).all()
+        if t == 0:
+            assert bool(d[9]) and infos[9]["terminal_observation"].shape == (1, 4, S, S)
+    venv._drain()
+    e2.check_status()
+    assert len(ptrs) <= 3  # recycled output sets, not 4 fresh 268 MB allocations
+
+
 def test_full_size_properties(ds):
     """BASELINE config 3 size (1024 envs, 128x128, ~5k-face meshes): properties that need no oracle."""
     from tests.parity_utils import make_case

@@ -160,6 +160,12 @@ def test_img_512_reference_default_size():
     _check(run_parity_case(n_env=1, img=512, seed=13, mesh="teapot"))
 
 
+def test_img_512_two_envs_5k_meshes():
+    """The reference's default size, batched, on ShapeNet-size meshes: n_env = 2 at 512 x 512, three
+    5 120-face objects per env, against the oracle."""
+    _check(run_parity_case(n_env=2, img=512, seed=21, mesh="synthetic"))
+
+
 def test_img_256():
     _check(run_parity_case(n_env=1, img=256, seed=8, mesh="teapot"))
 
@@ -198,6 +204,51 @@ def test_gradient_with_the_camera_inside_the_scene():
     _check(res)
     worst = max([a["e_gpu"] / (2.0 ** -24 * a["mass"]) for a in res["grad_arbiter"]] or [0.0])
     assert worst < 128.0, res["grad_arbiter"]  # half the arbiter's band: the excess is gone, not merely under the bar
+
+
+@pytest.mark.parametrize("K", [7, 99])
+def test_k_boundary_ties_between_coincident_faces_do_not_move_alpha(K):
+    """DESIGN 4 "Determinism": exact-z ties at the K boundary are broken by lane, then scan order here and by face index in
+    PyTorch3D.  Coincident faces tie EXACTLY in z - and have the same distance, hence the same 1 - p and the same
+    gradient terms: whichever twin is kept, alpha and d alpha are the same.  A mesh whose every face is listed twice,
+    with an ODD K so that the K-th / (K+1)-th nearest of a pixel with more than K candidates are the two twins of one
+    face: engine and oracle agree at 1e-4 on every pixel with NO tie accepted anywhere, and such boundaries do occur."""
+    import numpy as np
+
+    from oracle import p3d_restate as O
+    from occlusionenv_amd.meshes import MeshPool, SyntheticShapeNet
+    from tests.parity_utils import _Faces, oracle_env, run_engine
+
+    ds = SyntheticShapeNet(n_models=3, seed=77)
+    pool = MeshPool("cuda")
+    ids = [pool.add(ds.models[i][0], torch.cat([ds.models[i][1], ds.models[i][1]]), key=("twin", K, i)) for i in range(3)]
+    g = torch.Generator().manual_seed(5)
+    x2 = torch.randn(2, generator=g)
+    offsets = torch.zeros(2, 3, 3)
+    offsets[:, 1, 0], offsets[:, 1, 2] = x2, 1.0
+    offsets[:, 2, 0], offsets[:, 2, 2] = -x2, 2.0
+    case = dict(pool=pool, mesh_ids=torch.tensor([ids, ids[::-1]]), offsets=offsets, az=(torch.rand(2, generator=g) * 2 - 1) * 0.6,
+                actions=torch.randn(2, 2, generator=g))
+    S = 64
+    got = run_engine(case, S, faces_per_pixel=K)
+    split_pairs = 0
+    for i in range(2):
+        env = oracle_env(case, i, S, faces_per_pixel=K)
+        env.reset(azimuth=float(case["az"][i]))
+        a = case["actions"][i].clone().requires_grad_(True)
+        _, r, _, _ = env.step(a)
+        r.backward()
+        al = torch.stack([im[0, ..., 3] for im in env.alphas]).detach()
+        assert float((al - got["alphas"][i]).abs().max()) < TOL, (K, i)
+        assert float((a.grad - got["grad"][i]).norm()) <= 2e-4 * float(a.grad.norm()) + 1e-7
+        # the K boundary of a pixel with more than K candidates splits a pair of twins: count such pixels (oracle's own numbers)
+        faces = _Faces(env.objs[0][0], env.objs[0][1], env.R[0], env.T[0])
+        for y, x in torch.nonzero(al[0] > 0.5)[::2].tolist():
+            c = O.pixel_candidates(faces.fv, S, y, x, O.BLUR_RADIUS)
+            z = np.sort(c["z"][(c["flags"] & 2) != 0])
+            if z.size > K and z[K - 1] == z[K]:
+                split_pairs += 1
+    assert split_pairs >= 2, split_pairs
 
 
 def test_sorted_scan_order_build_matches_the_oracle():

@@ -6,6 +6,7 @@ actor moves and the clip branches are taken.  K in {1, 5, 80} epochs.
 
 CPU: ``BatchedPPO(fused=False)`` (the torch path) with N = 1.  GPU (-m gpu): ``occ_ppo_update`` through the C ABI.
 """
+import ast
 import os
 
 import numpy as np
@@ -15,7 +16,7 @@ import torch
 from occlusionenv_amd import ppo
 
 GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ppo_golden.npz"))
-HYPER = eval(str(GOLD["hyper"]))  # noqa: S307 - a dict literal written by the generator
+HYPER = ast.literal_eval(str(GOLD["hyper"]))  # a dict literal written by the generator
 HEADS = ("w_a", "b_a", "w_v", "b_v")
 
 
@@ -89,9 +90,12 @@ def test_torch_update_reproduces_the_references_heads(scen, K):
 @pytest.mark.parametrize("scen", ["enc", "dir"])
 @pytest.mark.parametrize("K", [1, 5, 80])
 def test_fused_update_reproduces_the_references_heads(scen, K):
-    """``occ_ppo_update`` (csrc/occ_ppo.hpp, through the C ABI) on the reference's buffer: heads to 1e-6 at K <= 5; at
-    K = 80 the critic to 1e-5 and the actor to 1 % of the distance the reference moved it (its trajectory passes
-    through the clip boundary of PPO.py:207, where a sample's last bit switches its gradient on or off)."""
+    """``occ_ppo_update`` (csrc/occ_ppo.hpp, through the C ABI) on the reference's buffer: heads to 1e-6 at K <= 5.  At
+    K = 80 the trajectory passes through the clip boundary of PPO.py:207, where a sample's last bit switches its gradient
+    on or off - the reference's OWN f32 run ends up to 4.7 % of the distance moved away from its float64 run (the
+    ``final64`` fixtures: the same update() on .double() heads, tests/golden/make_ppo_golden.py).  The float64 trajectory
+    arbitrates: the fused kernel may be no farther from it than TWICE what the reference's f32 run is (floor 1e-6), and
+    the critic - which no clip touches - stays within 1e-5 of the reference's f32 heads."""
     dev = "cuda:0"
     a = agent_from_fixture(scen, K, device=dev, fused=True)
     fill_from_fixture(a, scen, dev)
@@ -101,10 +105,13 @@ def test_fused_update_reproduces_the_references_heads(scen, K):
         err, moved = float((p.detach() - ref).abs().max()), float((ref - ini).abs().max())
         if K <= 5:
             assert err <= 1e-6, (k, K, err)
-        elif k in ("w_v", "b_v"):
+            continue
+        f64 = gold(scen, f"final64_{k}_K{K}", dev)
+        e_fused = float((p.detach().double() - f64).abs().max())
+        e_ref32 = float((ref.double() - f64).abs().max())
+        assert e_fused <= 2.0 * e_ref32 + 1e-6, (k, K, e_fused, e_ref32, moved)
+        if k in ("w_v", "b_v"):
             assert err <= 1e-5, (k, K, err)
-        else:
-            assert err <= max(1e-5, 1e-2 * moved), (k, K, err, moved)
     vl = GOLD[f"{scen}_vloss_K{K}"]
     assert abs(st["value_loss_first"] - vl[0]) <= 2e-6 * max(1.0, abs(vl[0]))
     assert abs(st["value_loss_last"] - vl[-1]) <= 1e-5 * max(1.0, abs(vl[-1]))
