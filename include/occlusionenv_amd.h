@@ -61,8 +61,9 @@ extern "C" {
 #define OCC_LOG_CAP 12288  /* candidate-log entries per persistent wave (20 B each); a log about to fill up is compacted
                               in place to every overflowing pixel's K nearest.  Must be >= 64*OCC_MAX_K + 2048 + 64 */
 #endif
-#define OCC_LOG_ENTRY_BYTES 28 /* (depth key u32, pixel | face sequence << 6 u32) + payload (1-p, p dd/del, p dd/daz) f32 x3
-                                  + 8 B of the selection's compacted copy of the entries of the pixels that hold more than K */
+#define OCC_LOG_ENTRY_BYTES 30 /* (depth key u32, pixel | face sequence << 6 u32) + payload (1-p, p dd/del, p dd/daz) f32 x3
+                                  + 8 + 2 B of the selection's compacted copy of the entries of the pixels that hold more than K
+                                  (the entry again, and its index in the log) */
 #define OCC_MAX_K 128      /* largest faces_per_pixel the fused path accepts */
 
 /* occ_camera modes */
@@ -126,7 +127,7 @@ typedef struct OccWorkspace {
     uint32_t* queue;    /* (8,16) one work-queue head per XCD group, a 64-B line each (zeroed by occ_render) */
     float* lists;       /* (n_slots, OCC_LOG_CAP*OCC_LOG_ENTRY_BYTES) per-wave K-buffer = wave-compacted candidate log:
                            OCC_LOG_CAP payloads of 12 B, then OCC_LOG_CAP (key, tag) pairs of 8 B (structure of arrays), then
-                           OCC_LOG_CAP x 8 B for the exact top-K's compacted copy of the entries it has to rank */
+                           OCC_LOG_CAP x (8 + 2) B for the exact top-K's compacted copy of the entries it has to rank */
     float* partials;    /* (n_env,ceil(S*S/256),4) per-block loss / gradient partial sums */
     int32_t* status;    /* (n_env) OCC_STATUS_* bits, OR-ed in; caller clears */
     int32_t* offsets;   /* (8*3*ceil(n_env/8)+1) rect order only (order == NULL): first work item of every (env, object), XCD-major */

@@ -18,7 +18,7 @@ CAM_STRIDE = 48
 REC_STRIDE = 32
 TILE = 8
 LOG_CAP = 12288
-LOG_ENTRY_BYTES = 28
+LOG_ENTRY_BYTES = 30
 MAX_K = 128
 CAM_STEP, CAM_LOOKAT, CAM_POSITION = 0, 1, 2
 RENDER_SOFT, RENDER_HARD, RENDER_GRAD = 1, 2, 4

@@ -56,7 +56,8 @@
 // OCC_LOG_CAP (include/occlusionenv_amd.h): log entries per wave; must hold a compacted log (64 * OCC_MAX_K) plus the
 // pairs of one batch
 static_assert(OCC_LOG_CAP >= 64 * OCC_MAX_K + 2048 + 64, "OCC_LOG_CAP too small");
-static_assert(OCC_LOG_ENTRY_BYTES == 28, "12 B payload + 8 B (key, tag) + 8 B (key, tag, index) of the selection's own compacted copy");
+static_assert(OCC_LOG_ENTRY_BYTES == 30, "12 B payload + 8 B (key, tag) + 8 B (key, tag) + 2 B (log index) of the selection's own compacted copy");
+static_assert(OCC_LOG_CAP % 8 == 0, "the regions of a wave's log stay 16-byte aligned");
 #define OCC_LOG_BYTES ((size_t)OCC_LOG_CAP * OCC_LOG_ENTRY_BYTES)
 
 constexpr int kT2 = 8;         // tile side in pixels (== OCC_TILE)
@@ -99,15 +100,15 @@ struct WaveLog {
     uint2* __restrict__ kt;    // (order-preserving depth key, pixel of the tile 0..63 | face sequence number << 6)
     // Round 5: what the selection's LATER sweeps read.  Its first sweep (the first histogram pass) copies the entries of
     // the pixels that hold more than K candidates - 63 % of the log of a tile that needs selection on the bench - into
-    // this region, in log order: (key, pixel | low twelve bits of the face sequence number << 6 | log index << 18).  The
-    // other histogram passes and the final sweep then visit those rows only.  (Twelve bits tell the faces of a 64-entry
-    // row apart as long as the row spans fewer than 4 096 faces; the copying pass checks that - a dense object's pruned
-    // log can be that sparse - and a tile that fails the check is swept in the log itself, as before round 5.)
+    // this region, in log order and unchanged, with every entry's index in the log (where its payload is) beside it in
+    // ix2.  The other histogram passes and the final sweep then visit those rows only.
+    // (A first version packed the index and twelve bits of the face sequence number into the tag: a dense object's
+    // pruned log can be so sparse that a 64-entry row of the copy spans thousands of faces - test_sorted_scan_order_build
+    // caught two pixels - and guarding the packing with a span check in the copying loop cost 8 % of the kernel.)
     uint2* __restrict__ kt2;
+    uint16_t* __restrict__ ix2;
 };
-static_assert(OCC_LOG_CAP <= 16384, "the compacted copy keeps the log index in fourteen bits");
-constexpr uint32_t kSeqBitsB = 12;                       // bits of the face sequence number in a compacted entry
-constexpr uint32_t kSeqSpanB = (1u << kSeqBitsB) - 64u;  // faces a row of the compacted copy may span
+static_assert(OCC_LOG_CAP <= 65536, "the compacted copy keeps the log index in sixteen bits");
 
 // Accumulator slot of pixel pix (= 8 py + px) in copy cpy.  A 16-byte LDS access is served 16 lanes at a time, one per
 // residue of the slot index mod 16: the column is rotated by 3 every second row and the copy stride is 1 mod 16, so that
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
         lg.pay = reinterpret_cast<LogPay*>(base);
         lg.kt = reinterpret_cast<uint2*>(base + (size_t)OCC_LOG_CAP * 12);
         lg.kt2 = reinterpret_cast<uint2*>(base + (size_t)OCC_LOG_CAP * 20);
+        lg.ix2 = reinterpret_cast<uint16_t*>(base + (size_t)OCC_LOG_CAP * 28);
     }
     ciptr offs = as_const(P.ws.offsets);
     ciptr ord = as_const(reinterpret_cast<const int*>(P.ws.order));  // null: rect order through offs
@@ -402,9 +404,6 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 const uint32_t ovf_lo = (uint32_t)ovf_m, ovf_hi = (uint32_t)(ovf_m >> 32);
                 const uint32_t L0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)L);  // (pass 0: L and sh are still the tile's, in every lane)
                 const uint32_t sh0 = (uint32_t)__builtin_amdgcn_readfirstlane(sh);
-                uint32_t row_first = 0u;  // lower bound of the face sequence numbers in the copy's open row (wave-uniform)
-                int n2_open = -1;         // that row
-                bool wide = false;        // some row of the copy may span too many faces for its twelve bits
                 auto bump_copy = [&](const int e0, const uint2 (&kt)[kSweepU]) __attribute__((always_inline)) {
 #pragma unroll
                     for (int u = 0; u < kSweepU; ++u) {
@@ -413,27 +412,28 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                         bool ov = false;
                         if (kt[u].y != kNoEntry) {
                             const uint32_t px = kt[u].y & 63u;
+#ifdef OCC_EXP_NO_P1S  // A/B build: the window looked up in LDS as in the later passes
+                            const uint2 w = s_sel[px];
+                            ov = w.y < 32u;
+                            if (ov) {
+                                const uint32_t d = (kt[u].x - w.x) >> w.y;
+                                if (kt[u].x >= w.x && d < (1u << kSelBits)) atomicAdd(&hist[px * kSelStride + (d >> 1)], 1u << (16 * (d & 1u)));
+                            }
+#else
                             ov = (((px & 32u) ? ovf_hi : ovf_lo) >> (px & 31u)) & 1u;
                             if (ov) {
                                 const uint32_t d = (kt[u].x - L0) >> sh0;
                                 if (kt[u].x >= L0 && d < (1u << kSelBits)) atomicAdd(&hist[px * kSelStride + (d >> 1)], 1u << (16 * (d & 1u)));
                             }
+#endif
                         }
                         const unsigned long long m = __ballot(ov);
-                        if (ov) lg.kt2[n2 + lane_rank(m)] = make_uint2(kt[u].x, (kt[u].y & ((64u << kSeqBitsB) - 1u)) | (uint32_t)(e0 + u * 64 + lane) << (6 + kSeqBitsB));
+                        if (ov) {
+                            const int wpos = n2 + lane_rank(m);
+                            lg.kt2[wpos] = kt[u];
+                            lg.ix2[wpos] = (uint16_t)(e0 + u * 64 + lane);
+                        }
                         n2 += __popcll(m);
-                    }
-                    // The span of the copy's 64-entry rows, bounded per GROUP of log rows (face sequence numbers do not decrease
-                    // along the log): the row that was open when the group began reaches at most the group's last face; a row
-                    // opened inside the group starts no earlier than the group's first.  (Per ballot and exact, with two more
-                    // ballots and a branch, this check cost the kernel 25 %: it serialises the group's four rows.)
-                    const uint32_t g_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(kt[0].y >> 6));
-                    const uint32_t g_last = e0 + kGroup <= nsrc ? (uint32_t)__builtin_amdgcn_readlane((int)(kt[kSweepU - 1].y >> 6), 63) : (uint32_t)fseq_base;
-                    if (n2_open < 0) row_first = g_first;  // (the very first row)
-                    wide = wide || (n2 > 0 && g_last - row_first >= kSeqSpanB);
-                    if ((n2 >> 6) != n2_open) {
-                        row_first = g_first;
-                        n2_open = n2 >> 6;
                     }
                 };
                 {
@@ -444,19 +444,25 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     for (int e0 = 0; e0 < nsrc; e0 += kRingG * kGroup) {
 #pragma unroll
                         for (int gi = 0; gi < kRingG; ++gi) {
+#ifdef OCC_EXP_NO_CLOG  // A/B build: no compacted copy, every sweep reads the log itself
+                            bump(ring[gi]);
+#else
                             if (!compact && pass == 0) bump_copy(e0 + gi * kGroup, ring[gi]);
                             else bump(ring[gi]);
+#endif
                             load_group(e0 + (kRingG + gi) * kGroup, ring[gi]);
                         }
                     }
                 }
-                if (!compact && pass == 0 && !wide) {
+#ifndef OCC_EXP_NO_CLOG
+                if (!compact && pass == 0) {
                     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the copy is in memory before it is swept
                     src = lg.kt2;
                     nsrc = n2;
                     fmt_b = true;
                     OCC_STAT(13, n2);  // entries in the compacted copy
                 }
+#endif
                 pass += 1;
                 wave_lds_sync();
                 OCC_T(11);  // selection: histogram sweeps
@@ -609,10 +615,21 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 // payloads have had a group's work to arrive.  Groups are applied in log order, sub-passes as in the evaluation
                 // rounds: the sums come out bit for bit as before.
                 uint2 ring[kRingG][kSweepU];
+                uint32_t ringx[kRingG][kSweepU];  // the entries' indices in the log (their payloads' places)
+                auto load_index = [&](const int e0, uint32_t (&ix)[kSweepU]) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int u = 0; u < kSweepU; ++u) {
+                        const int e = e0 + u * 64 + lane;
+                        ix[u] = fmt_b ? (e < nsrc ? (uint32_t)lg.ix2[e] : 0u) : (uint32_t)e;
+                    }
+                };
                 uint32_t ptag[kSweepU];  // tag | 1 << 31 of an entry that is re-accumulated, else 0
                 LogPay ppay[kSweepU];
 #pragma unroll
-                for (int gi = 0; gi < kRingG; ++gi) load_group(gi * kGroup, ring[gi]);
+                for (int gi = 0; gi < kRingG; ++gi) {
+                    load_group(gi * kGroup, ring[gi]);
+                    load_index(gi * kGroup, ringx[gi]);
+                }
 #pragma unroll
                 for (int u = 0; u < kSweepU; ++u) {
                     ptag[u] = 0u;
@@ -622,7 +639,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #pragma unroll
                     for (int u = 0; u < kSweepU; ++u) {
                         const bool act = (ptag[u] >> 31) != 0u;
-                        const uint32_t tag = ptag[u] & 0x7FFFFFFFu;  // pixel | face sequence number << 6 (all of it, or its low twelve bits)
+                        const uint32_t tag = ptag[u] & 0x7FFFFFFFu;  // pixel | face sequence number << 6
                         const uint32_t grp = tag >> (6 + kCopyBits);
                         const int slot = acc_slot((int)((tag >> 6) & (uint32_t)(kCopies - 1)), (int)(tag & 63u));
                         unsigned long long rem = __ballot(act);
@@ -649,7 +666,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                         }
                     }
                 };
-                auto decide = [&](const int e0, const uint2 (&kt)[kSweepU]) __attribute__((always_inline)) {
+                auto decide = [&](const uint2 (&kt)[kSweepU], const uint32_t (&ix)[kSweepU]) __attribute__((always_inline)) {
                     uint32_t readdm = 0u;
 #pragma unroll
                     for (int u = 0; u < kSweepU; ++u) {  // decisions in log order (ties are served first come)
@@ -664,8 +681,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                                 } else if (((kt[u].x - w.x) >> shp) == 0u) {
                                     if ((w.y >> 8) == (uint32_t)kList) {
                                         const uint32_t sl = atomicAdd(&s_lcnt[px], 1u);
-                                        if (sl < (uint32_t)kListCap)  // (key, log index)
-                                            blist[px * kListCap + sl] = make_uint2(kt[u].x, fmt_b ? kt[u].y >> (6 + kSeqBitsB) : (uint32_t)(e0 + u * 64 + lane));
+                                        if (sl < (uint32_t)kListCap) blist[px * kListCap + sl] = make_uint2(kt[u].x, ix[u]);  // (key, log index)
                                     } else {
                                         r = (int)atomicSub(&s_take[px], 1u) > 0;  // the first `take` arrivals are kept
                                     }
@@ -677,9 +693,8 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #pragma unroll
                     for (int u = 0; u < kSweepU; ++u) {
                         const bool r = (readdm >> u) & 1u;
-                        // index of the entry in the log itself (where its payload is), and its tag without that index
-                        const uint32_t e = fmt_b ? kt[u].y >> (6 + kSeqBitsB) : (uint32_t)(e0 + u * 64 + lane);
-                        ptag[u] = r ? ((fmt_b ? kt[u].y & ((64u << kSeqBitsB) - 1u) : kt[u].y) | 0x80000000u) : 0u;
+                        const uint32_t e = ix[u];  // index of the entry in the log itself: where its payload is
+                        ptag[u] = r ? (kt[u].y | 0x80000000u) : 0u;
 #ifdef OCC_EXP_FS_NO_PAY  // timing experiment only (results void): what the final sweep's dependent payload loads cost
                         ppay[u] = LogPay{__uint_as_float(0x3f800000u | (r ? 1u : 0u)), 0.f, (float)e};
 #else
@@ -691,8 +706,9 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #pragma unroll
                     for (int gi = 0; gi < kRingG; ++gi) {
                         apply();  // the group before this one
-                        decide(e0 + gi * kGroup, ring[gi]);
+                        decide(ring[gi], ringx[gi]);
                         load_group(e0 + (kRingG + gi) * kGroup, ring[gi]);
+                        load_index(e0 + (kRingG + gi) * kGroup, ringx[gi]);
                     }
                 }
                 apply();  // the last group
