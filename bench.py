@@ -145,7 +145,11 @@ def build_env(workload: str, n_env: int, img: int, seed: int, pool_models: int =
         ds = None
     else:
         # pool of 1 024 procedural ShapeNet-size meshes, seed 1234 (94 MB on the device: beyond L2)
-        ds = SyntheticShapeNet(n_models=pool_models, seed=1234, mixed=(workload == "mixed"))
+        # (cached under the temp dir: eight ranks of a node start together, and ~26 s of mesh generation per rank and run
+        # is start-up nobody needs twice)
+        import tempfile
+
+        ds = SyntheticShapeNet(n_models=pool_models, seed=1234, mixed=(workload == "mixed"), cache_dir=tempfile.gettempdir())
     venv = SimpleVecEnv([(lambda: OcclusionEnv(ds, img_size=img)) for _ in range(n_env)])
     venv.seed(seed)
     return venv, ds

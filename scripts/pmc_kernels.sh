@@ -20,7 +20,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  (cd /tmp && timeout -k 10 240 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/p$i" -- "$PY" "$ROOTD/bench.py" --steps 6 --warmup 2 --no-cpu-baseline "$@" > "$OUT/p$i.log" 2>&1)
+  (cd /tmp && timeout -k 10 240 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/p$i" -- "$PY" "$ROOTD/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --fresh-steps 0 "$@" > "$OUT/p$i.log" 2>&1)
   echo "pmc pass $i rc $?"
 done
 python - "$OUT" <<'PY'

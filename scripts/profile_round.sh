@@ -13,8 +13,8 @@ export TMPDIR=/tmp
 # ELF binary - not a pyenv / conda shim or wrapper script that would exec again (forbidden on this pool once the GPU is open)
 PY=$(readlink -f "$(command -v python)")
 if [ "$(head -c 4 "$PY" | tail -c 3)" != "ELF" ]; then echo "python resolves to $PY, which is not an ELF binary: refusing to profile through a wrapper" >&2; exit 3; fi
-ARGS="--steps 10 --warmup 2 --no-cpu-baseline"          # PMC passes: counters are per launch, every kernel is replayed
-TRACE_ARGS="--steps 40 --warmup 4 --no-cpu-baseline"    # --stats averages over the warm-up launches too: dilute them
+ARGS="--steps 10 --warmup 2 --no-cpu-baseline --fresh-steps 0"          # PMC passes: counters are per launch, every kernel is replayed
+TRACE_ARGS="--steps 40 --warmup 4 --no-cpu-baseline --fresh-steps 0"    # --stats averages over the warm-up launches too: dilute them
 timeout -k 10 500 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 prof() {  # subdir, rocprofv3 options..., then bench args after --
   d=$1; shift
