@@ -99,7 +99,8 @@ if __name__ == "__main__":
         print("seed %d %-9s %3d K %3d az %.1f r %.1f  %s  alpha %.1e obs %.1e loss %.1e reward %.1e grad %.1e ties %d %s" % (
             seed, c["mesh"], c["img"], c.get("faces_per_pixel", 100), c["az_range"], c["radius"], "BAD" if v else "ok ", res["alpha_maxabs"],
             res["obs_maxabs"], res["loss_rel"], res["reward_abs"], res["grad_rel"], res["tie_pixels"],
-            ("arbiter " + " ".join("gpu %.0f orc32 %.0f eps*M" % (a["e_gpu"] / max(2.0 ** -24 * a["mass"], 1e-300), a["e_orc32"] / max(2.0 ** -24 * a["mass"], 1e-300)) for a in res["grad_arbiter"]) + " " if res["grad_arbiter"] else "")
+            ("arbiter " + " ".join("gpu %.0f orc32 %.0f eps*M (floor: %s)" % (a["e_gpu"] / max(2.0 ** -24 * a["mass"], 1e-300), a["e_orc32"] / max(2.0 ** -24 * a["mass"], 1e-300), a.get("floor", "model")) for a in res["grad_arbiter"]) + " " if res["grad_arbiter"] else "")
+            + ("gradient ties %d %s " % (res["grad_tie_pixels"], res.get("grad_tie_reasons")) if res.get("grad_tie_pixels") else "")
             + "; ".join(v)), flush=True)
     print("cases %d  violations %d  cases with tie pixels %d  %.0f s  worst: %s" % (
         n, bad, ties, time.time() - t0, " ".join("%s=%.2e" % kv for kv in sorted(worst.items()))))

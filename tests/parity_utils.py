@@ -67,6 +67,7 @@ TVERT = 2.5e-7      # vertex-coordinate noise between the two fp32 projections (
 TVIEW = 5e-7        # view-space coordinate noise between the two fp32 camera transforms (1 ulp at |coordinate| in [4, 8))
 TTEXEL = 1e-3       # barycentric * R within this of a texel-cell boundary
 GRAD_NOISE_ULPS = 256.0  # fp32 noise floor of the action gradient, in units of eps * (L1 mass of its pixel terms)
+GRAD_ORC32_FACTOR = 2.0  # ... or, where the f32 ORACLE itself is farther than that from the f64 one, this x ITS distance (round 5)
 TEAPOT = os.path.join(ROOT, "data", "teapot.obj")
 
 
@@ -185,8 +186,16 @@ def grad_check(g_gpu, g32, g64_fn, mass_fn):
     mass = mass_fn()
     e_gpu = float((g_gpu.double() - g64).norm())
     e_orc = float((g32.double() - g64).norm())
-    bound = TOL * float(g64.norm()) + GRAD_NOISE_ULPS * 2.0 ** -24 * mass
-    return dict(ok=e_gpu <= bound, rel32=grel, g64=float(g64.norm()), mass=mass, e_gpu=e_gpu, e_orc32=e_orc, bound=bound)
+    # The noise floor of an f32 evaluation of this sum: the model (GRAD_NOISE_ULPS eps M) - or what the reference's own
+    # precision MEASURABLY does: where the f32 oracle (torch autograd + the C backward, the reference's arithmetic) is itself
+    # farther from the f64 oracle than the model allows, the model is not the floor there (round 5's wide sweep: seeds 9140
+    # and 9215, f32 oracle at 1 060 and 28 255 eps M, the engine at 2 454 and 27 840), and the engine is held to
+    # GRAD_ORC32_FACTOR x the f32 oracle's own distance.  `floor` says which of the two applied.
+    model = GRAD_NOISE_ULPS * 2.0 ** -24 * mass
+    measured = GRAD_ORC32_FACTOR * e_orc
+    bound = TOL * float(g64.norm()) + max(model, measured)
+    return dict(ok=e_gpu <= bound, rel32=grel, g64=float(g64.norm()), mass=mass, e_gpu=e_gpu, e_orc32=e_orc, bound=bound,
+                floor="model" if model >= measured else "f32 oracle")
 
 
 # ---- tie classifier -----------------------------------------------------------------------------------------------
@@ -271,7 +280,8 @@ def snapshot_records(eng):
         n, base = int(nrec[eo]), int(rec_off[eo])
         r = rec[base * 32: (base + n) * 32].cpu().numpy().reshape(n, 32).copy()
         out.append(dict(fv=torch.from_numpy(r[:, :9].reshape(n, 3, 3).copy()), ids=r[:, 9].view(np.int32).copy(),
-                        flags=r[:, 10].view(np.int32).copy()))
+                        flags=r[:, 10].view(np.int32).copy(),
+                        tan=r[:, 20:32].reshape(n, 3, 4).copy()))  # per vertex: d x/d el, d y/d el, d x/d az, d y/d az
     return out
 
 
@@ -576,6 +586,33 @@ def run_parity_case(n_env=2, img=64, seed=0, mesh="teapot", az_range=0.6, check_
         # fp32 cancellation noise or a real error?  beyond 1e-4 the f64 oracle arbitrates (module docstring)
         gc = grad_check(got_w["grad"][i], g, lambda: _oracle_grad64(case, i, img, radius, w, faces_per_pixel),
                         lambda: gradient_mass(got_w, i, w))
+        if not gc["ok"] and shader == "flat":
+            # GRADIENT TIES (tests/grad_explain.py): which pixels make the gradient differ, and is each of them a near-tie
+            # by the oracle's own numbers - the closest edge of a face undecided within the positional noise, or a near /
+            # z-clipped face whose gradient the engine's own records reproduce?  Those pixels are weighted out on both
+            # sides, like image ties, and the SAME criterion is applied again.
+            from tests import grad_explain as GX
+
+            ex = GX.explain_gradient(case, i, img, faces_per_pixel, radius, got_w, w)
+            assert ex["selfcheck"] < 1e-8, ("the f64 forward sweep does not reproduce the f64 oracle's autograd", ex["selfcheck"])
+            n_gt = int(ex["ties"].sum())
+            res["grad_tie_pixels"] = max(res.get("grad_tie_pixels", 0), n_gt)
+            res.setdefault("grad_tie_reasons", {}).update({k: res.get("grad_tie_reasons", {}).get(k, 0) + v for k, v in ex["reasons"].items()})
+            if n_gt:
+                if REASON_LOG is not None:
+                    REASON_LOG.extend(("grad", -1, int(y), int(x), ("gradient: " + "+".join(sorted(ex["reasons"])),)) for y, x in torch.nonzero(ex["ties"]).tolist())
+                w2 = w * (~ex["ties"]).float()
+                wts2 = weights.clone()
+                wts2[i] = w2
+                got2 = run_engine(case, img, radius=radius, faces_per_pixel=faces_per_pixel, pixel_weight=wts2, shader=shader)
+                env2 = oracle_env(case, i, img, shader, faces_per_pixel)
+                env2.reset(radius=radius, azimuth=float(case["az"][i]))
+                l0 = torch.sum(w2 * env2.image[0, ..., 3].detach() ** 2)
+                a2 = case["actions"][i].clone().requires_grad_(True)
+                env2.step(a2)
+                ((l0 - torch.sum(w2 * env2.image[0, ..., 3] ** 2)) / (l0 + 1)).backward()
+                gc = grad_check(got2["grad"][i], a2.grad, lambda: _oracle_grad64(case, i, img, radius, w2, faces_per_pixel),
+                                lambda: gradient_mass(got2, i, w2))
         res["grad_rel"] = max(res["grad_rel"], gc["rel32"])
         if "g64" in gc:
             res["grad_arbiter"].append(dict(gc, env=i))
@@ -631,6 +668,14 @@ def max_upstream_pixels(img, n_objects=3):
     return max(8, int(UPSTREAM_FRAC * img * img * n_objects))
 
 
+def max_grad_tie_pixels(img, n_objects=3):
+    """Bound on the pixels weighted out as gradient ties per env (tests/grad_explain.py): near-ties are rounding
+    coincidences, a handful per image."""
+    from tests.grad_explain import GRAD_TIE_FRAC
+
+    return max(4, int(GRAD_TIE_FRAC * img * img * n_objects))
+
+
 def violations(res, tol=TOL):
     """What the parity tests, smoke() and scripts/parity_sweep.py all check; returns a list of failures (empty = ok)."""
     bad = []
@@ -648,6 +693,8 @@ def violations(res, tol=TOL):
               "loss0_rel", "reward_abs"):
         if not res[k] < tol:
             bad.append("%s = %.3e" % (k, res[k]))
+    if res.get("grad_tie_pixels", 0) > max_grad_tie_pixels(res["img"]):
+        bad.append("too many gradient-tie pixels: %d (%s)" % (res["grad_tie_pixels"], res.get("grad_tie_reasons")))
     if res["grad_excess"] > 0.0:  # beyond 1e-4 of the f32 oracle AND rejected by the f64 arbiter (module docstring)
         bad.append("grad: %s" % [a for a in res["grad_arbiter"] if not a["ok"]])
     return bad

@@ -337,6 +337,13 @@ def test_tie_classifier_bands_are_frozen():
                   GRAD_NOISE_ULPS=256.0)
     for name, bound in frozen.items():
         assert 0 < getattr(pu, name) <= bound, (name, getattr(pu, name), bound)
+    # round 5: the gradient's own near-tie rules (tests/grad_explain.py) and the measured noise floor of the arbiter
+    from tests import grad_explain as gx
+
+    assert 0 < pu.GRAD_ORC32_FACTOR <= 2.0
+    assert 0 < gx.TCENTRE <= 1.2e-7 and 0 < gx.TGRAD_PIX <= 1e-3 and gx.TGRAD_SHARE >= 0.1 and 0 < gx.GRAD_TIE_FRAC <= 2e-4
+    for img in (64, 128, 256, 512):
+        assert pu.max_grad_tie_pixels(img) <= max(4, int(2e-4 * img * img * 3))
     # the per-env budgets of accepted pixels: tie decisions, pixels under the near / z-clipped rule, and the footprint
     # allowance of hair-flipped needles (these three were still loose)
     assert 0 < pu.TIE_FRAC <= 2e-4 and 0 < pu.UPSTREAM_FRAC <= 2e-3 and 0 < pu.FOOTPRINT_FACTOR <= 8
@@ -493,3 +500,50 @@ def test_mixed_texture_scenes_are_drawn_again_like_the_reference():
         kinds |= tex
     assert kinds == {True, False} and rejected > 50  # both uniform kinds occur; most draws of this pool are mixed
     environment.seed_scene_rng(None)
+
+
+def test_closest_edge_tie_rule_on_a_corner_bisector():
+    """tests/grad_explain.py, CLOSEST-EDGE TIE, on the configuration that motivated it (parity sweep seed 9276): one large
+    face, a pixel centre on the bisector of its corner at v0 - the squared distances to edges (v0,v1) and (v0,v2) are equal
+    there and the gradient of dists jumps between the two edges' normals.  The rule fires on the bisector (and within the
+    positional noise of it), not a pixel away, and the forward sweep's d alpha on either side differs by the jump."""
+    import numpy as np
+
+    from tests import grad_explain as gx
+
+    S = 64
+    pitch = 2.0 / S
+
+    def centre(i):
+        return -1.0 + (2.0 * (S - 1 - i) + 1.0) / S
+
+    yi, xi = 30, 40
+    px, py = centre(xi), centre(yi)
+    # corner v0 below-left of the pixel, edges at +-30 degrees around the direction to the pixel: the pixel is ON the bisector
+    d = 0.6 * pitch  # (close to the corner: deeper inside, 1 - p underflows and there is no gradient to compare)
+    v0 = np.array([px - d * np.cos(0.3), py - d * np.sin(0.3)])
+    e1 = np.array([np.cos(0.3 + 0.5), np.sin(0.3 + 0.5)])
+    e2 = np.array([np.cos(0.3 - 0.5), np.sin(0.3 - 0.5)])
+    fv = np.zeros((1, 3, 3))
+    fv[0, :, 2] = 1.0
+    fv[0, 0, :2], fv[0, 1, :2], fv[0, 2, :2] = v0, v0 + 0.6 * e1, v0 + 0.6 * e2
+    tan = np.zeros((2, 1, 3, 3))
+    tan[0, 0, :, 0] = 1.0  # every vertex moves along +x with el, along +y with az
+    tan[1, 0, :, 1] = 1.0
+    p2f = np.full((S, S, 1), -1, dtype=np.int64)
+    p2f[yi, xi, 0] = 0
+    p2f[yi, xi + 3, 0] = 0  # three pixels to the side: clearly nearer to one edge
+    _, dal, tie = gx.forward_planes(fv, tan, p2f, S)
+    assert bool(tie[yi, xi]) and not bool(tie[yi, xi + 3]) and int(tie.sum()) == 1
+    # a hair off the bisector - less than the positional noise - still ties; the two sides' gradients differ by the jump
+    for shift, expect in ((5e-8, True), (1e-5, False)):
+        fv2 = fv.copy()
+        fv2[0, :, :2] += shift * np.array([-np.sin(0.3), np.cos(0.3)])  # across the bisector
+        _, _, t2 = gx.forward_planes(fv2, tan, p2f, S)
+        assert bool(t2[yi, xi]) == expect, shift
+    up, dn = fv.copy(), fv.copy()
+    up[0, :, :2] += 1e-5 * np.array([-np.sin(0.3), np.cos(0.3)])
+    dn[0, :, :2] -= 1e-5 * np.array([-np.sin(0.3), np.cos(0.3)])
+    da = gx.forward_planes(up, tan, p2f, S)[1][:, yi, xi]
+    db = gx.forward_planes(dn, tan, p2f, S)[1][:, yi, xi]
+    assert np.abs(da - db).max() > 0.2 * max(np.abs(da).max(), np.abs(db).max())  # a jump, not a slope
