@@ -285,46 +285,54 @@ __global__ __launch_bounds__(1024) void occ_recoff_kernel(OccScene sc, long long
     if (order_hdr && tid < kOrdBlk) order_hdr[tid] = 0u;
     if (!rec_off) return;  // fixed record layout: nothing to lay out
     const int M = 3 * sc.n_env;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (int base = 0; base < M; base += 1024) {
-        const int i = base + tid;
-        long long c = 0;
+    // ONE round (round 5; until then ceil(M / 1024) dependent rounds of scan + two barriers each): every thread takes
+    // `per` CONSECUTIVE entries, the block scans the threads' totals once, the entries' offsets follow from the thread's.
+    const int per = (M + 1023) / 1024;
+    const int i0 = tid * per;
+    long long tsum = 0;
+    for (int k = 0; k < per; ++k) {
+        const int i = i0 + k;
         if (i < M && !(sc.skip && sc.skip[i / 3])) {
+            const int mesh = sc.scene_mesh[i];
+            const int nF = sc.mesh_face_off[mesh + 1] - sc.mesh_face_off[mesh];
+            tsum += ((2ll * nF + 63) >> 6) << 6;
+        }
+    }
+    long long incl = tsum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    long long woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const long long v = s_part[w];
+        if (w < wave) woff += v;
+        tot += v;
+    }
+    long long off = woff + incl - tsum;  // offset of this thread's first entry
+    for (int k = 0; k < per; ++k) {
+        const int i = i0 + k;
+        if (i >= M) break;
+        long long c = 0;
+        if (!(sc.skip && sc.skip[i / 3])) {
             const int mesh = sc.scene_mesh[i];
             const int nF = sc.mesh_face_off[mesh + 1] - sc.mesh_face_off[mesh];
             c = ((2ll * nF + 63) >> 6) << 6;
         }
-        long long incl = c;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const long long t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
+        if (off + c > rec_total) {  // does not fit: empty span at the end of the buffer
+            rec_off[i] = rec_total;
+            if (c) atomicOr(&status[i / 3], OCC_STATUS_REC_OVERFLOW);
+        } else {
+            rec_off[i] = off;
         }
-        if (lane == 63) s_part[wave] = incl;
-        __syncthreads();
-        long long woff = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const long long v = s_part[w];
-            if (w < wave) woff += v;
-            tot += v;
-        }
-        const long long carry = s_carry;
-        if (i < M) {
-            const long long off = carry + woff + incl - c;
-            if (off + c > rec_total) {  // does not fit: empty span at the end of the buffer
-                rec_off[i] = rec_total;
-                if (c) atomicOr(&status[i / 3], OCC_STATUS_REC_OVERFLOW);
-            } else {
-                rec_off[i] = off;
-            }
-        }
-        __syncthreads();
-        if (tid == 0) s_carry = carry + tot;
-        __syncthreads();
+        off += c;
     }
-    if (tid == 0) rec_off[M] = min(s_carry, rec_total);
+    if (tid == 0) rec_off[M] = min(tot, rec_total);
+    (void)s_carry;
 }
 
 // Objects with many visible faces (>= kSortMin records: a pixel then collects far more than K candidates) get

@@ -43,7 +43,11 @@ against the f32 oracle; where that fails, the f64 build arbitrates with the fp32
     |g_hip - g_f64| <= 1e-4 |g_f64| + 256 eps M,
 M = the L1 mass of the per-pixel terms, pushed through |J| / objectMass like the gradient itself, computed from the
 engine's per-object alpha / d alpha planes (recomposing the NET sum from the same planes reproduces the engine's
-gradient to 1e-8, so the planes are what the gradient is made of).
+gradient to 1e-8, so the planes are what the gradient is made of).  Round 5: (i) where the f32 ORACLE is itself farther from
+the f64 one than that model floor, the floor is GRAD_ORC32_FACTOR x the f32 oracle's own distance (grad_check); (ii) a
+gradient that fails is examined PIXEL BY PIXEL (tests/grad_explain.py): pixels whose d alpha difference matters must be
+closest-edge ties or near / z-clipped faces by the oracle's own numbers, are weighted out on both sides like image ties
+(budget max_grad_tie_pixels) and the same criterion is applied again.
 """
 from __future__ import annotations
 
