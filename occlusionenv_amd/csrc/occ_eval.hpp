@@ -136,7 +136,7 @@ __device__ int g_dbg_fault[8];
 #endif
 
 #ifdef OCC_DBG_STATS  // diagnostic build only: loop trip counts of the raster kernel
-__device__ unsigned long long g_dbg_stats[16];
+__device__ unsigned long long g_dbg_stats[32];
 #define OCC_STAT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); /* all lanes: v may hold a ballot */ if (lane == 0) atomicAdd(&g_dbg_stats[i], v_); } while (0)
 #else
 #define OCC_STAT(i, v) do { } while (0)

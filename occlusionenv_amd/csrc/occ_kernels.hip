@@ -101,8 +101,8 @@ extern "C" int occ_profile_read(double* ms_sum, int* launches) {
 
 #ifdef OCC_DBG_STATS
 extern "C" int occ_debug_stats(unsigned long long* out16) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(occ::g_dbg_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return 2;
-    unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(occ::g_dbg_stats), 32 * sizeof(unsigned long long)) != hipSuccess) return 2;  // (32 slots)
+    unsigned long long z[32] = {};
     return hipMemcpyToSymbol(HIP_SYMBOL(occ::g_dbg_stats), z, sizeof(z)) == hipSuccess ? 0 : 2;
 }
 #endif

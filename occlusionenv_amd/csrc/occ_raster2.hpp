@@ -184,14 +184,15 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
     __shared__ float4 s_pool[kRecF4 + kPairCap / 16];
     float4* const s_rec = s_pool;
     uint8_t* const s_flag = reinterpret_cast<uint8_t*>(s_pool + kRecF4);  // pair map: 1 = first pair of a face
-    // selection scratch on top of the same pool: 64 x kSelStride histogram dwords, then four 64-entry arrays
-    static_assert(sizeof(float4) * (kRecF4 + kPairCap / 16) >= 64 * kSelStride * 4 + 64 * 4 * 4, "selection scratch does not fit");
+    // selection scratch on top of the same pool: 64 x kSelStride histogram dwords, then five 64-entry arrays
+    static_assert(sizeof(float4) * (kRecF4 + kPairCap / 16) >= 64 * kSelStride * 4 + 64 * 5 * 4, "selection scratch does not fit");
     static_assert((64 * kSelStride) % 4 == 0 && 64 * kSelStride * 4 >= 64 * kListCap * 8, "alignment of the arrays behind the histograms / boundary lists on top of them");
     uint32_t* const s_selbase = reinterpret_cast<uint32_t*>(s_pool) + 64 * kSelStride;
     uint2* const s_sel = reinterpret_cast<uint2*>(s_selbase);            // selection window (low key, shift | 255 = idle)
     uint32_t* const s_take = s_selbase + 128;
     uint32_t* const s_lcnt = s_selbase + 192;   // boundary-list fill counts (final selection) ...
     uint32_t* const s_kmax2 = s_selbase + 192;  // ... or the kept entries' largest key (in-loop compaction): never both
+    uint32_t* const s_arrive = s_selbase + 256; // kept entries per pixel so far (final sweep: which copy takes the next one)
     // two hit lists: while one batch is evaluated the next one is already scanned and its records are in flight
     __shared__ int s_hit[2 * kStg2];               // record index of every staged face
     __shared__ uint2 s_box[2 * kStg2];             // its pixel bbox (xl | yl << 16, xh | yh << 16), then (pre, geometry)
@@ -505,6 +506,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             s_sel[lane] = make_uint2(L, ovf ? (uint32_t)sh | ((uint32_t)mode << 8) : 255u);
             s_take[lane] = mode == kAll ? 0x7FFFFFFFu : (uint32_t)max(need, 0);
             s_lcnt[lane] = 0u;  // kList: entries collected so far / compaction: largest kept key
+            s_arrive[lane] = 0u;
             acc2 = make_float4(1.f, 0.f, 0.f, 0.f);
             if (ovf) {  // its accumulated state is void: the copies now collect the kept entries (product, sums, count)
 #pragma unroll
@@ -576,7 +578,11 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                         while (rem) {
                             OCC_STAT(12, 1);          // RMW sub-passes of the final sweep
                             const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)grp, __ffsll(rem) - 1);
+#ifdef OCC_EXP_ONE_SUBPASS
+                            const bool mine = act;
+#else
                             const bool mine = act && grp == g0;
+#endif
                             if (mine) {
                                 float4 a = s_acc[slot];
                                 a.x *= pv[u].q;
@@ -639,7 +645,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
 #pragma unroll
                     for (int u = 0; u < kSweepU; ++u) {
                         const bool act = (ptag[u] >> 31) != 0u;
-                        const uint32_t tag = ptag[u] & 0x7FFFFFFFu;  // pixel | face sequence number << 6
+                        const uint32_t tag = ptag[u] & 0x7FFFFFFFu;  // pixel | copy << 6 | sub-pass << 8 (decide)
                         const uint32_t grp = tag >> (6 + kCopyBits);
                         const int slot = acc_slot((int)((tag >> 6) & (uint32_t)(kCopies - 1)), (int)(tag & 63u));
                         unsigned long long rem = __ballot(act);
@@ -651,7 +657,11 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                         while (rem) {
                             OCC_STAT(12, 1);  // RMW sub-passes of the final sweep
                             const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)grp, __ffsll(rem) - 1);
+#ifdef OCC_EXP_ONE_SUBPASS
+                            const bool mine = act;
+#else
                             const bool mine = act && grp == g0;
+#endif
                             if (mine) {
                                 float4 a = s_acc[slot];
                                 a.x *= ppay[u].q;
@@ -668,8 +678,10 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                 };
                 auto decide = [&](const uint2 (&kt)[kSweepU], const uint32_t (&ix)[kSweepU]) __attribute__((always_inline)) {
                     uint32_t readdm = 0u;
+                    uint32_t rtag[kSweepU];  // pixel | copy << 6 | sub-pass << 8 of a kept entry
 #pragma unroll
                     for (int u = 0; u < kSweepU; ++u) {  // decisions in log order (ties are served first come)
+                        rtag[u] = 0u;
                         if (kt[u].y != kNoEntry) {
                             const uint32_t px = kt[u].y & 63u;
                             const uint2 w = s_sel[px];
@@ -686,7 +698,25 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                                         r = (int)atomicSub(&s_take[px], 1u) > 0;  // the first `take` arrivals are kept
                                     }
                                 }
-                                if (r) readdm |= 1u << u;
+                                if (r) {
+                                    readdm |= 1u << u;
+#ifndef OCC_EXP_FS_SEQ_COPIES
+                                    // Which copy takes the entry and in which sub-pass: by the pixel's ARRIVAL INDEX i among its
+                                    // kept entries (one counter per pixel; entries of one pixel in one row get consecutive
+                                    // indices, in lane = log order - the rule the tie counters above already rest on).  Copy
+                                    // i & 3; an entry waits for the sub-pass (i - index of the pixel's first entry in this row)
+                                    // >> 2: four entries of a pixel go at once, and a row holds more than four only rarely -
+                                    // against one sub-pass per group of four FACES present in the row (5.3 per row on the bench:
+                                    // a row of kept entries spans dozens of faces).  The copy of an entry depends on nothing but
+                                    // the pixel's own sequence of kept entries: results do not depend on how a launch splits its
+                                    // tiles or on which other pixels are under selection.
+                                    const uint32_t base = s_arrive[px];                 // (before any lane's add of this row)
+                                    const uint32_t i = atomicAdd(&s_arrive[px], 1u);
+                                    rtag[u] = px | ((i & 3u) << 6) | (((i - base) >> 2) << 8);
+#else
+                                    rtag[u] = kt[u].y;
+#endif
+                                }
                             }
                         }
                     }
@@ -694,7 +724,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                     for (int u = 0; u < kSweepU; ++u) {
                         const bool r = (readdm >> u) & 1u;
                         const uint32_t e = ix[u];  // index of the entry in the log itself: where its payload is
-                        ptag[u] = r ? (kt[u].y | 0x80000000u) : 0u;
+                        ptag[u] = r ? (rtag[u] | 0x80000000u) : 0u;
 #ifdef OCC_EXP_FS_NO_PAY  // timing experiment only (results void): what the final sweep's dependent payload loads cost
                         ppay[u] = LogPay{__uint_as_float(0x3f800000u | (r ? 1u : 0u)), 0.f, (float)e};
 #else
@@ -1078,10 +1108,52 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
                             // (one cross-lane read instead of redoing acc_slot's arithmetic), the copy adds a constant
                             const int slot = __shfl(myslot, pix, 64) + (int)__umul24((uint32_t)(f & (kCopies - 1)), (uint32_t)kAccStride);
                             const int grp = (f - f_first) >> kCopyBits;
+#ifdef OCC_EXP_ONE_SUBPASS  // timing experiment only (results void): every round applied in ONE sub-pass - the ceiling for more copies
+                            const int nsub = 1;
+#else
                             const int nsub = ((f_last - f_first) >> kCopyBits) + 1;
+#endif
+#ifdef OCC_DBG_STATS  // what more accumulator copies would buy: sub-passes per round with 4 / 5 / 6 / 8 copies
+                            {
+                                const int nf_ = f_last - f_first + 1;
+                                OCC_STAT(14, 1);  // rounds with at least one accepted pair
+                                OCC_STAT(15, (nf_ + 3) / 4);
+                                OCC_STAT(16, (nf_ + 4) / 5);
+                                OCC_STAT(17, (nf_ + 5) / 6);
+                                OCC_STAT(18, (nf_ + 7) / 8);
+                                OCC_STAT(19, nf_);
+                                // ... and if only the faces of ACCEPTED pairs counted (first to last accepted lane)
+                                const int fa_ = __builtin_amdgcn_readlane(f, __ffsll(m) - 1), fb_ = __builtin_amdgcn_readlane(f, 63 - __builtin_clzll(m));
+                                OCC_STAT(20, (fb_ - fa_ + 4) / 4);
+                                OCC_STAT(21, (fb_ - fa_ + 6) / 6);
+                                OCC_STAT(22, __popcll(m));  // accepted pairs
+                            }
+#endif
+#ifdef OCC_DBG_STATS  // exact conflict schedules (what a per-round rank by LDS atomics would give)
+                            {
+                                __shared__ uint32_t s_dbgrk[64];
+                                auto maxrank = [&](const bool on, const uint32_t k) {  // k < 256: counter (byte) index
+                                    s_dbgrk[lane] = 0u;
+                                    wave_lds_sync();
+                                    const uint32_t old = atomicAdd(&s_dbgrk[k >> 2], on ? 1u << (8u * (k & 3u)) : 0u);
+                                    wave_lds_sync();
+                                    const uint32_t rk = on ? (old >> (8u * (k & 3u))) & 255u : 0u;
+                                    return (int)wave_minmax_u32_dpp<true>(rk);
+                                };
+                                const uint32_t kc = (uint32_t)((f & 3) * 64 + pix), kp = (uint32_t)pix;
+                                OCC_STAT(23, maxrank(live, kc) + 1);          // copy = face & 3, schedule by rank among LIVE lanes of (pixel, copy)
+                                OCC_STAT(24, maxrank(acc, kc) + 1);           // ... among ACCEPTED lanes
+                                OCC_STAT(25, maxrank(live, kp) / 4 + 1);      // copy = rank & 3 among live lanes of the pixel
+                                OCC_STAT(26, maxrank(acc, kp) / 4 + 1);       // ... among accepted lanes (= arrival index)
+                            }
+#endif
                             auto subpasses = [&](auto with_bound) __attribute__((always_inline)) {
                                 for (int sp = 0; sp < nsub; ++sp) {
+#ifdef OCC_EXP_ONE_SUBPASS
+                                    if (acc) {
+#else
                                     if (acc && grp == sp) {
+#endif
                                         float4 a = s_acc[slot];
                                         a.x *= c1.q;
                                         if (GRAD) {
