@@ -36,10 +36,13 @@
 //     contiguously; every entry bumps the LDS histogram of ITS pixel (odd stride per pixel: a face's pixels bump the same
 //     bucket); the pixel's owner lane (lane = pixel) scans its 32 buckets and narrows its window; sweeps keep two groups
 //     of four 512-byte loads in flight (a sweep with one dependent load per iteration is pure memory latency).
-//     Afterwards one more sweep re-accumulates the kept entries of the overflowing pixels - products and sums exactly
-//     as the evaluation rounds form them - into the pixel's four accumulator copies by plain read-modify-write, one
-//     sub-pass per group of four faces (the tag's sequence number): three LDS float atomics per entry, colliding on the
-//     pixel, cost 0.28 of 2.39 ms; ranking the lanes of a row by pixel with six ballots was slower still.  When the log
+//     Afterwards one more sweep re-accumulates the kept entries of the overflowing pixels into the pixel's four
+//     accumulator copies by plain read-modify-write.  Round 5: the copy is chosen by the pixel's ARRIVAL INDEX i among
+//     its kept entries (a per-pixel LDS counter, bumped in log order): copy i & 3, sub-pass (i - first index of the
+//     pixel in this row) >> 2 - four entries of a pixel per sub-pass (2.7 sub-passes per 64-entry row on the bench: a
+//     row's entries crowd on a dozen pixels; one sub-pass per group of four FACES present in the row was 3.5, and 6 %
+//     of the kernel slower).  (Three LDS float atomics per entry, colliding on the pixel, cost 0.28 of 2.39 ms in
+//     round 2; ranking the lanes of a row by pixel with six ballots was slower still.)  When the log
 //     fills up (thousands of candidates per pixel: far cameras, dense meshes) the same machinery keeps each overflowing
 //     pixel's K nearest and compacts the log in place; pruning bounds for front-to-back-sorted (dense) objects.
 //   * TWELVE RESIDENT WAVES PER CU: three per SIMD is what <= 168 VGPRs allow (the evaluation alone holds 132-147, DESIGN
@@ -89,6 +92,12 @@ constexpr int kListCap = 8;    // boundary-bucket entries per pixel that the own
 #endif
 constexpr int kCopyBits = OCC_ACC_COPY_BITS;  // accumulator copies = 1 << kCopyBits, chosen by (face sequence number & (kCopies - 1))
 constexpr int kCopies = 1 << kCopyBits;
+// (Round 5, measured: SIX copies of 12 bytes - product and tangent sums in arrays of their own, candidate count and key bound
+// as one word per pixel bumped by non-returning LDS atomics, the same 12.7 KB - bring a round from 2.21 to 1.54 sub-passes and
+// the kernel from 1.896 to 1.867 ms against FOUR copies in that format; this format, with its single 16-byte access per
+// sub-pass and the count riding along, runs at 1.869: nothing gained, not kept.  The lanes of a round crowd on about ten
+// pixels - seven tiny faces covering the same ones - so even an exact conflict schedule needs 1.9 sub-passes with four copies.
+// Final sweep: sub-passes over a whole group of four rows at once (four reads in flight per sub-pass): 1.930 vs 1.887, worse.)
 constexpr int kAccStride = 65; // accumulator slots per copy: one per pixel, +1 so that the copies of a pixel differ mod 16 (acc_slot)
 
 constexpr uint32_t kNoEntry = 0xFFFFFFFFu;  // tag of a slot past the end of the log (a tag is pixel | face sequence number << 6)
