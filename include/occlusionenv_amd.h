@@ -124,7 +124,7 @@ typedef struct OccWorkspace {
     uint32_t* scan;     /* (n_env,3,rec_cap,4) per record, in face order: pixel bbox xl|yl<<16, xh|yh<<16|corner-cut bits<<28 (img <= 2048), key of its nearest vertex depth, record index (the raster scan order unless re-sorted, see rec_bbox) */
     int32_t* nrec;      /* (n_env,3) */
     int32_t* objrect;   /* (n_env,3,4) block rect bx0,by0,bx1,by1 (inclusive, OCC_BLOCK-pixel units) */
-    uint32_t* queue;    /* (8,16) one work-queue head per XCD group, a 64-B line each (zeroed by occ_render) */
+    uint32_t* queue;    /* (8,32) one work-queue head per XCD group, a 128-B line each (zeroed by occ_render) */
     float* lists;       /* (n_slots, OCC_LOG_CAP*OCC_LOG_ENTRY_BYTES) per-wave K-buffer = wave-compacted candidate log:
                            OCC_LOG_CAP payloads of 12 B, then OCC_LOG_CAP (key, tag) pairs of 8 B (structure of arrays), then
                            OCC_LOG_CAP x (8 + 2) B for the exact top-K's compacted copy of the entries it has to rank */

@@ -117,6 +117,12 @@ extern "C" int occ_debug_time(unsigned long long* out112) {
 }
 #endif
 
+#ifdef OCC_DBG_ENDS
+extern "C" int occ_debug_ends(unsigned long long* out16384) {
+    return hipMemcpyFromSymbol(out16384, HIP_SYMBOL(occ::g_dbg_ends), 4 * 4096 * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
+}
+#endif
+
 #ifdef OCC_DBG_BOUNDS
 extern "C" int occ_debug_fault(int* out8) {
     return hipMemcpyFromSymbol(out8, HIP_SYMBOL(occ::g_dbg_fault), 8 * sizeof(int)) == hipSuccess ? 0 : 2;
@@ -152,7 +158,7 @@ extern "C" int occ_workspace_query(const OccScene* scene, int n_slots, OccWorksp
     out->rec_cbox_bytes = N * 3 * ((cap + 63) / 64) * 4 * sizeof(uint32_t);
     out->nrec_bytes = N * 3 * sizeof(int32_t);
     out->objrect_bytes = N * 3 * 4 * sizeof(int32_t);
-    out->queue_bytes = 8 * 16 * sizeof(uint32_t);  // eight queue heads, one 64-B line each
+    out->queue_bytes = 8 * kQueueStride * sizeof(uint32_t);  // eight queue heads, one 128-B line each
     out->lists_bytes = (size_t)n_slots * OCC_LOG_BYTES;  // per-wave K-buffer: the compacted candidate log
     const size_t S2 = (size_t)scene->img * scene->img;
     out->partials_bytes = N * ((S2 + 255) / 256) * 4 * sizeof(float);

@@ -164,6 +164,13 @@ __device__ unsigned long long g_dbg_time[112];
         atomicAdd(&g_dbg_time[32 + b_], 1ull); atomicAdd(&g_dbg_time[64 + b_], t_lastd); \
         if (t_w0 - first_ > 5000ull) atomicAdd(&g_dbg_time[27], 1ull); \
         atomicMin(&g_dbg_time[96 + my_xcc], t_w0); atomicMax(&g_dbg_time[104 + my_xcc], t_e); } } while (0)
+#elif defined(OCC_DBG_ENDS)  // light diagnostic build: per wave (start, end of its last item, exit, items), plain stores - no atomics
+__device__ unsigned long long g_dbg_ends[4 * 4096];
+#define OCC_T_DECL const unsigned long long t_w0 = __builtin_amdgcn_s_memrealtime(); unsigned long long t_item = t_w0, t_items = 0
+#define OCC_T(i) do { } while (0)
+#define OCC_T_ITEM(heavy) do { t_item = __builtin_amdgcn_s_memrealtime(); t_items += 1; } while (0)
+#define OCC_T_FLUSH do { if (lane == 0 && blockIdx.x < 4096) { g_dbg_ends[4 * blockIdx.x] = t_w0; g_dbg_ends[4 * blockIdx.x + 1] = t_item; \
+        g_dbg_ends[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime(); g_dbg_ends[4 * blockIdx.x + 3] = t_items | ((unsigned long long)my_xcc << 32); } } while (0)
 #else
 #define OCC_T_DECL do { } while (0)
 #define OCC_T(i) do { } while (0)
@@ -228,6 +235,10 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
     const int myslot = acc_slot(0, lane);  // accumulator slot (copy 0) of the pixel this lane owns
     OCC_T_DECL;
 
+    // (Round 5, -DOCC_DBG_ENDS: the waves' last items end within 2.7 % of the launch; then every wave walks the eight heads with
+    // a device-scope RMW each, 35-40 us from its last item to its exit.  A line of "exhausted" flags - byte stores, one load -
+    // brings that to 12 us and the launch not forward: the last items just end later.  Not kept.  The heads 128 bytes apart
+    // instead of 64 - one L2 line each - is what did count: 1.894 -> 1.873 ms.)
     // (Claiming the NEXT item when an item starts, so that the queue head's atomic round trip flies during the item's work:
     // measured in round 4, 1.944 -> 1.995 ms.  A wave that holds two items at a time undoes the point of the cost-ordered
     // queues near the end of the launch.  Not kept.)
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(64, OCC_RASTER2_WAVES_PER_SIMD) void occ_raster2_ke
             const int qq = (my_xcc + qround) & 7;
             const int qbeg = (ord ? ord[qq] : offs[qq * mq]) << sl, qend = (ord ? ord[qq + 1] : offs[(qq + 1) * mq]) << sl;
             int t = qend;
-            if (lane == 0 && qbeg < qend) t = qbeg + (int)atomicAdd(P.ws.queue + qq * 16, 1u);
+            if (lane == 0 && qbeg < qend) t = qbeg + (int)atomicAdd(P.ws.queue + qq * kQueueStride, 1u);
             t = __builtin_amdgcn_readfirstlane(t);
             if (t < qend) {
                 item = t >> sl;

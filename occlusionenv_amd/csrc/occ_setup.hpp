@@ -281,7 +281,7 @@ __global__ __launch_bounds__(1024) void occ_recoff_kernel(OccScene sc, long long
                        cam_args.cam_pos_out2, n);
         return;
     }
-    if (tid < 8 * 16) queue[tid] = 0u;
+    if (tid < 8) queue[tid * kQueueStride] = 0u;
     if (order_hdr && tid < kOrdBlk) order_hdr[tid] = 0u;
     if (!rec_off) return;  // fixed record layout: nothing to lay out
     const int M = 3 * sc.n_env;

@@ -58,7 +58,7 @@ def test_workspace_query_and_argument_checks_need_no_gpu():
     assert lib.occ_workspace_query(ctypes.byref(sc), 64, ctypes.byref(sizes)) == 0
     assert sizes.rec_bytes == 4 * 3 * 1000 * nat.REC_STRIDE * 4 and sizes.rec_bbox_bytes == 4 * 3 * 1000 * 16 and sizes.scan_bytes == sizes.rec_bbox_bytes
     assert sizes.partials_bytes == 4 * 64 * 16 and sizes.n_slots == 64
-    assert sizes.offsets_bytes == 25 * 4 and sizes.queue_bytes == 512 and sizes.obj_alpha_bytes == 4 * 3 * 128 * 128 * 4 and sizes.obj_grad_bytes == 2 * sizes.obj_alpha_bytes
+    assert sizes.offsets_bytes == 25 * 4 and sizes.queue_bytes == 1024 and sizes.obj_alpha_bytes == 4 * 3 * 128 * 128 * 4 and sizes.obj_grad_bytes == 2 * sizes.obj_alpha_bytes
     assert sizes.lists_bytes == 64 * nat.LOG_CAP * nat.LOG_ENTRY_BYTES  # sized for the log only
     # work-item order: 512 header words + 32 per (env, object) + 3 per tile (rank|class, and the 8-byte item)
     assert sizes.order_bytes == (512 + 4 * 3 * 32 + 4 * 3 * 16 * 16 * 3) * 4
