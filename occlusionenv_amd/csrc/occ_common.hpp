@@ -42,8 +42,6 @@ __device__ __forceinline__ uint32_t ord_class_bound(int cls) {
     return fl == 0 ? 2u : (half ? 2u << fl : 3u << (fl - 1));
 }
 
-// a * b for operands below 2^24 as ONE full-rate instruction.  Opaque on purpose: left to itself hipcc folds the
-// surrounding subtraction into a multiply by a negative constant, which needs the quarter-rate v_mul_lo_u32.
 // Work-queue heads (OccWorkspace.queue): one per XCD group, kQueueStride words apart - a 128-byte L2 line each (at 64 bytes
 // two heads shared a line: 1.894 -> 1.873 ms for the raster kernel of the bench; 256 B or 4 KB apart: the same).
 #ifndef OCC_QUEUE_STRIDE
@@ -51,6 +49,8 @@ __device__ __forceinline__ uint32_t ord_class_bound(int cls) {
 #endif
 constexpr int kQueueStride = OCC_QUEUE_STRIDE;
 
+// a * b for operands below 2^24 as ONE full-rate instruction.  Opaque on purpose: left to itself hipcc folds the
+// surrounding subtraction into a multiply by a negative constant, which needs the quarter-rate v_mul_lo_u32.
 __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) {
     uint32_t r;
     asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
